@@ -1,0 +1,148 @@
+/*
+ * osi.h — C ABI of libosi_hip.so: the MI355X (gfx950) implementation of the open-set ImageNet training hot path.
+ *
+ * The reference (AIML-IfI/openset-imagenet) is pure Python and has no operator / plugin / FFI layer of its own
+ * (SURVEY.md §8b); the arithmetic it runs lives in torch / torchvision calls. Each entry point below therefore cites
+ * the reference CALL SITE whose arithmetic it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain C: raw device pointers, ints, floats, one opaque stream handle (a hipStream_t); no torch types.
+ *   - every function returns OSI_OK (0) or a negative OSI_ERR_* code; nothing throws across the ABI.
+ *   - no allocation, no host synchronisation, no implicit stream: the caller owns every buffer (workspace sizes
+ *     come from the matching *_workspace query) and passes the stream to launch on. Launch functions are
+ *     re-entrant and safe to capture into a hipGraph.
+ *   - activations are fp32 NHWC ([B][H][W][C], C contiguous); conv weights are fp32 KRSC ([Cout][R][S][Cin]) —
+ *     byte-identical to a torch OIHW tensor kept in channels_last strides, which is how the Python module owns them.
+ *   - all pointers must be 16-byte aligned; channel counts must be multiples of 4 (64 for conv GEMM dimensions).
+ */
+#ifndef OSI_H
+#define OSI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSI_OK 0
+#define OSI_ERR_ARG (-1)    /* shape / pointer / alignment precondition violated; nothing was launched */
+#define OSI_ERR_LAUNCH (-2) /* the HIP runtime refused a launch or an attribute */
+#define OSI_ERR_STATE (-3)  /* executor called out of order (backward before forward, wrong batch, ...) */
+
+typedef void* osi_stream_t; /* hipStream_t */
+
+int osi_abi_version(void);            /* bumped on any signature change */
+const char* osi_build_arch(void);     /* "gfx950" */
+const char* osi_strerror(int code);
+
+/* ---- convolution (torchvision.models.resnet50 body constructed at openset_imagenet/model.py:17, run at model.py:37) --- */
+typedef struct {
+    int B, H, W, Cin; /* input  [B][H][W][Cin]   */
+    int Ho, Wo, Cout; /* output [B][Ho][Wo][Cout] */
+    int R, S, stride, pad;
+} osi_conv_desc;
+
+enum { OSI_TILE_AUTO = 0, OSI_TILE_128x128 = 1, OSI_TILE_128x64 = 2, OSI_TILE_64x128 = 3, OSI_TILE_64x64 = 4 };
+
+/* y = conv2d(x, w), bias-free. The 7x7 stem is described with Cin = 4 (image staged by osi_nchw3_to_nhwc4) and takes
+ * weights packed by osi_stem_weight_pack ([Cout][56 taps][4]). Otherwise Cin % 32 == 0, Cout % 64 == 0. */
+int osi_conv_fwd(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, osi_stream_t stream);
+/* dx (+)= conv2d_input_grad(dy, w). accumulate != 0 adds into dx (skip-connection sum). Cout % 32 == 0, Cin % 64 == 0. */
+int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, int tile,
+                   osi_stream_t stream);
+/* dw = conv2d_weight_grad(dy, x), deterministic split-K through `ws` (size from osi_conv_wgrad_workspace). The stem writes
+ * the packed [Cout][224] form; osi_stem_grad_unpack converts to [Cout][7][7][3]. */
+size_t osi_conv_wgrad_workspace(const osi_conv_desc* d);
+int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, float* dw, void* ws, size_t ws_bytes,
+                   osi_stream_t stream);
+int osi_stem_weight_pack(const float* w_krsc3, float* w_packed, int Cout, osi_stream_t stream);
+int osi_stem_grad_unpack(const float* g_packed, float* g_krsc3, int Cout, osi_stream_t stream);
+
+/* ---- BatchNorm2d in training mode + ReLU + residual (torchvision Bottleneck under model.py:37; train() at train.py:125) --- */
+size_t osi_bn_workspace(int M, int C);
+/* batch statistics of y[M][C]: mean, invstd = 1/sqrt(biased var + eps), scale = gamma*invstd, shift = beta - mean*scale;
+ * running stats updated with the unbiased variance when running_mean/var are non-NULL. */
+int osi_bn_train_stats(const float* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                       void* ws, size_t ws_bytes, osi_stream_t stream);
+/* eval mode (validate(), train.py:142-196): scale/shift from the running statistics */
+int osi_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
+                       int C, float* scale, float* shift, osi_stream_t stream);
+/* out = [relu](y*scale + shift [+ residual]) */
+int osi_bn_apply(const float* y, const float* residual, const float* scale, const float* shift, float* out, int M, int C,
+                 int relu, osi_stream_t stream);
+/* g = dout * (act > 0) (act NULL: g = dout); dgamma, dbeta; dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).
+ * gmasked (optional) receives g, the gradient that continues along the skip connection. dy may alias dout. */
+size_t osi_bn_backward_workspace(int M, int C);
+int osi_bn_backward(const float* dout, const float* act, const float* y, const float* mean, const float* invstd,
+                    const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
+                    size_t ws_bytes, osi_stream_t stream);
+
+/* ---- pooling / layout (ResNet.maxpool, ResNet.avgpool, flatten; image batch of train.py:128) --- */
+int osi_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int B, int H, int W, osi_stream_t stream);
+/* idx: B*Ho*Wo*C bytes (argmax position 0..8 per element) */
+int osi_maxpool3x3s2_fwd(const float* x, float* y, void* idx, int B, int H, int W, int C, osi_stream_t stream);
+int osi_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, int B, int H, int W, int C, osi_stream_t stream);
+int osi_avgpool_fwd(const float* x, float* y, int B, int HW, int C, osi_stream_t stream);
+int osi_avgpool_bwd(const float* dy, float* dx, int B, int HW, int C, osi_stream_t stream);
+
+/* ---- head: resnet_base.fc (model.py:19-20) and logits (model.py:23-26) --- */
+int osi_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int O, osi_stream_t stream);
+int osi_linear_bwd(const float* dy, const float* x, const float* w, float* dx, int dx_accumulate, float* dw, float* db, int B,
+                   int K, int O, osi_stream_t stream);
+
+/* ---- losses (losses.py:16-29; train.py:343; train.py:344-347; objectosphere term: SURVEY.md §8 a9) --- */
+enum { OSI_LOSS_ENTROPIC = 0, OSI_LOSS_SOFTMAX = 1, OSI_LOSS_GARBAGE = 2 };
+/* loss (1 float) and dlogits = dJ/dlogits in one launch. features != NULL adds alpha/B * sum r_i^2 and writes dfeatures.
+ * dlogits may be NULL (validation: loss only). */
+int osi_loss_fwd_bwd(int mode, const float* logits, const long long* target, int B, int C, float unk_weight,
+                     long long ignore_index, const float* class_weights, const float* features, int F, float xi, float alpha,
+                     float* loss, float* dlogits, float* dfeatures, osi_stream_t stream);
+int osi_softmax(const float* logits, float* out, int B, int C, osi_stream_t stream); /* train.py:177 */
+
+/* ---- optimizer + arena utilities (train.py:356-359 construction, train.py:127,139 zero_grad/step) --- */
+int osi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                  float beta2, float eps, long long step, float grad_scale, osi_stream_t stream);
+int osi_sgd_step(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum, int first_step,
+                 float grad_scale, osi_stream_t stream);
+int osi_fill_f32(float* p, size_t n, float value, osi_stream_t stream);
+int osi_scale_f32(float* p, size_t n, float s, osi_stream_t stream);
+int osi_i64_add(long long* p, int n, long long inc, osi_stream_t stream);
+
+/* ---- whole-network executor: ResNet50.forward (model.py:28-39) and its autograd backward (train.py:138) ---------------
+ * One call enqueues the full forward (or a range of backward stages) on `stream`. The caller owns three flat arenas whose
+ * layout is reported by the *_info queries:
+ *   params   fp32   all 161 weight tensors in nn.Module registration order (conv KRSC, BN gamma/beta, fc, logits)
+ *   grads    fp32   same layout as params
+ *   buffers  fp32   BN running_mean / running_var (53 x 2)      nbt: int64[53] num_batches_tracked
+ * and a workspace of osi_resnet50_workspace_bytes() holding activations, saved statistics and scratch. */
+typedef struct osi_resnet50* osi_resnet50_t;
+
+int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, int out_features, int logit_bias);
+void osi_resnet50_destroy(osi_resnet50_t net);
+int osi_resnet50_num_tensors(osi_resnet50_t net);             /* parameter tensors */
+/* name: reference state_dict key ("resnet_base.layer1.0.conv1.weight"); shape in torch order (OIHW for convs), ndim <= 4;
+ * offset/numel in floats inside the params/grads arena */
+int osi_resnet50_tensor_info(osi_resnet50_t net, int i, char* name, int name_cap, int* ndim, int* shape, size_t* offset,
+                             size_t* numel);
+size_t osi_resnet50_param_floats(osi_resnet50_t net);         /* arena length, multiple of 4 */
+int osi_resnet50_num_bn(osi_resnet50_t net);
+/* BN layer j: prefix ("resnet_base.layer1.0.bn1"), channel count, offsets of running_mean / running_var in `buffers` */
+int osi_resnet50_bn_info(osi_resnet50_t net, int j, char* prefix, int cap, int* C, size_t* rm_offset, size_t* rv_offset);
+size_t osi_resnet50_buffer_floats(osi_resnet50_t net);
+size_t osi_resnet50_workspace_bytes(osi_resnet50_t net);
+int osi_resnet50_num_stages(osi_resnet50_t net);              /* backward stages (gradient buckets), head first */
+/* floats [lo, hi) of the grads arena that are final once backward stage s has run */
+int osi_resnet50_stage_grad_range(osi_resnet50_t net, int s, size_t* lo, size_t* hi);
+
+/* image: [B][3][H][W] fp32 NCHW as the reference feeds it. training != 0: batch statistics + running-stat update. */
+int osi_resnet50_forward(osi_resnet50_t net, const float* params, float* buffers, long long* nbt, const float* image,
+                         void* workspace, float* logits, float* features, int training, osi_stream_t stream);
+/* runs backward stages [stage_lo, stage_hi) given dJ/dlogits and (optionally, may be NULL) dJ/dfeatures */
+int osi_resnet50_backward(osi_resnet50_t net, const float* params, float* grads, void* workspace, const float* dlogits,
+                          const float* dfeatures, int stage_lo, int stage_hi, osi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSI_H */

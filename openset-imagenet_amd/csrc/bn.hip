@@ -1,0 +1,352 @@
+// BatchNorm2d (training mode) on NHWC fp32 activations, fused with ReLU / residual add / ReLU-mask.
+//
+// Replaces the 53 torch.nn.BatchNorm2d + 49 ReLU + 16 residual adds that torchvision's ResNet-50 runs under
+// openset_imagenet/model.py:37 with model.train() set at openset_imagenet/train.py:125 (reference).
+// Semantics kept: normalise with the biased batch variance, update running_var with the unbiased one,
+// momentum 0.1 convention running = (1-m)*running + m*batch, eps inside the sqrt.
+//
+// All kernels are HBM-bound streams over [M = B*H*W][C] with C contiguous: 16-byte accesses, each lane owns
+// 4 consecutive channels, row-lanes of a workgroup walk the rows, cross-row-lane reduction through LDS.
+// Statistics use shifted sums per workgroup (shift = first row of the chunk) and a weighted Chan merge of
+// the per-workgroup (mean, M2), so there is no E[x^2]-E[x]^2 cancellation in fp32.
+#include "osi_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct RowSplit { int CV, RL, G; };  // float4 columns per pass, row lanes, column groups
+__host__ __device__ inline RowSplit row_split(int C) {
+    RowSplit s;
+    int c4 = C / 4;
+    s.CV = c4 < NT ? c4 : NT;
+    s.RL = NT / s.CV;
+    s.G = (c4 + s.CV - 1) / s.CV;
+    return s;
+}
+
+// ---- statistics -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_bn_stats_partial(const float* __restrict__ y, int M, int C, int rows_per_blk,
+                                                        float* __restrict__ pmean, float* __restrict__ pm2) {
+    __shared__ f32x4 red[2][NT];
+    const RowSplit sp = row_split(C);
+    const int tid = threadIdx.x;
+    const int cv = tid % sp.CV, rl = tid / sp.CV;
+    const int r0 = blockIdx.x * rows_per_blk;
+    const int r1 = min(M, r0 + rows_per_blk);
+    const float n = (float)(r1 - r0);
+    const bool active = rl < sp.RL;
+    for (int g = 0; g < sp.G; ++g) {
+        const int c4 = g * sp.CV + cv;
+        const bool colok = active && c4 * 4 < C;
+        f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, shift = {0, 0, 0, 0};
+        if (colok) {
+            const f32x4* base = reinterpret_cast<const f32x4*>(y) + c4;
+            const size_t ld = C / 4;
+            shift = base[(size_t)r0 * ld];
+            int r = r0 + rl;
+            for (; r + 3 * sp.RL < r1; r += 4 * sp.RL) {
+                f32x4 v0 = base[(size_t)r * ld], v1 = base[(size_t)(r + sp.RL) * ld];
+                f32x4 v2 = base[(size_t)(r + 2 * sp.RL) * ld], v3 = base[(size_t)(r + 3 * sp.RL) * ld];
+                v0 -= shift; v1 -= shift; v2 -= shift; v3 -= shift;
+                s1 += (v0 + v1) + (v2 + v3);
+                s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            }
+            for (; r < r1; r += sp.RL) {
+                f32x4 v = base[(size_t)r * ld] - shift;
+                s1 += v; s2 += v * v;
+            }
+        }
+        red[0][tid] = s1; red[1][tid] = s2;
+        __syncthreads();
+        if (colok && rl == 0) {
+            for (int k = 1; k < sp.RL; ++k) { s1 += red[0][k * sp.CV + cv]; s2 += red[1][k * sp.CV + cv]; }
+            f32x4 mean = shift + s1 / n;
+            f32x4 m2 = s2 - s1 * s1 / n;
+            reinterpret_cast<f32x4*>(pmean + (size_t)blockIdx.x * C)[c4] = mean;
+            reinterpret_cast<f32x4*>(pm2 + (size_t)blockIdx.x * C)[c4] = m2;
+        }
+        __syncthreads();
+    }
+}
+
+// One workgroup = 32 channels x 8 partial lanes. mean = sum n_b mean_b / M ; M2 = sum M2_b + n_b (mean_b-mean)^2
+__global__ __launch_bounds__(NT) void k_bn_stats_final(const float* __restrict__ pmean, const float* __restrict__ pm2, int P,
+                                                      int rows_per_blk, int M, int C, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, float momentum,
+                                                      float* running_mean, float* running_var, float* __restrict__ mean_out,
+                                                      float* __restrict__ invstd_out, float* __restrict__ scale_out,
+                                                      float* __restrict__ shift_out) {
+    __shared__ float red[8][32];
+    __shared__ float smean[32];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const bool ok = c < C;
+    float acc = 0.f;
+    if (ok)
+        for (int b = pl; b < P; b += 8) {
+            float nb = (float)min(rows_per_blk, M - b * rows_per_blk);
+            acc += nb * pmean[(size_t)b * C + c];
+        }
+    red[pl][cl] = acc;
+    __syncthreads();
+    if (pl == 0) {
+        float s = 0.f;
+        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        smean[cl] = s / (float)M;
+    }
+    __syncthreads();
+    const float mean = smean[cl];
+    acc = 0.f;
+    if (ok)
+        for (int b = pl; b < P; b += 8) {
+            float nb = (float)min(rows_per_blk, M - b * rows_per_blk);
+            float d = pmean[(size_t)b * C + c] - mean;
+            acc += pm2[(size_t)b * C + c] + nb * d * d;
+        }
+    __syncthreads();
+    red[pl][cl] = acc;
+    __syncthreads();
+    if (pl == 0 && ok) {
+        float m2 = 0.f;
+        for (int k = 0; k < 8; ++k) m2 += red[k][cl];
+        float var = m2 / (float)M;
+        float invstd = 1.0f / sqrtf(var + eps);
+        mean_out[c] = mean; invstd_out[c] = invstd;
+        float sc = invstd * gamma[c];
+        scale_out[c] = sc; shift_out[c] = beta[c] - mean * sc;
+        if (running_mean) {
+            float unb = M > 1 ? m2 / (float)(M - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        }
+    }
+}
+
+// eval mode: scale/shift from running statistics
+__global__ void k_bn_eval_coeffs(const float* rm, const float* rv, const float* gamma, const float* beta, float eps, int C,
+                                 float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sc = gamma[c] * (1.0f / sqrtf(rv[c] + eps));
+    scale[c] = sc; shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---- apply: out = [relu]( y*scale + shift [+ res] ) ---------------------------------------------------
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(NT) void k_bn_apply(const f32x4* __restrict__ y, const f32x4* __restrict__ res,
+                                                const f32x4* __restrict__ scale, const f32x4* __restrict__ shift,
+                                                f32x4* __restrict__ out, size_t n4, int c4n) {
+    size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * NT;
+    for (; i < n4; i += step) {
+        int c4 = (int)(i % (size_t)c4n);
+        f32x4 v = y[i] * scale[c4] + shift[c4];
+        if (RES) v += res[i];
+        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        out[i] = v;
+    }
+}
+
+// ---- backward ---------------------------------------------------------------------------------------
+// g = dA * (act > 0) (act == nullptr: g = dA);  partial sums of g and g*xhat per workgroup
+__global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float* __restrict__ dA, const float* __restrict__ act,
+                                                      const float* __restrict__ y, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, int M, int C, int rows_per_blk,
+                                                      float* __restrict__ pdb, float* __restrict__ pdg) {
+    __shared__ f32x4 red[2][NT];
+    const RowSplit sp = row_split(C);
+    const int tid = threadIdx.x;
+    const int cv = tid % sp.CV, rl = tid / sp.CV;
+    const int r0 = blockIdx.x * rows_per_blk;
+    const int r1 = min(M, r0 + rows_per_blk);
+    const bool active = rl < sp.RL;
+    const size_t ld = C / 4;
+    for (int g = 0; g < sp.G; ++g) {
+        const int c4 = g * sp.CV + cv;
+        const bool colok = active && c4 * 4 < C;
+        f32x4 sb = {0, 0, 0, 0}, sg = {0, 0, 0, 0};
+        if (colok) {
+            const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4];
+            const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c4];
+            const f32x4* pd = reinterpret_cast<const f32x4*>(dA) + c4;
+            const f32x4* pa = act ? reinterpret_cast<const f32x4*>(act) + c4 : nullptr;
+            const f32x4* py = reinterpret_cast<const f32x4*>(y) + c4;
+            for (int r = r0 + rl; r < r1; r += sp.RL) {
+                f32x4 gv = pd[(size_t)r * ld];
+                if (pa) {
+                    f32x4 a = pa[(size_t)r * ld];
+                    gv.x = a.x > 0.f ? gv.x : 0.f; gv.y = a.y > 0.f ? gv.y : 0.f;
+                    gv.z = a.z > 0.f ? gv.z : 0.f; gv.w = a.w > 0.f ? gv.w : 0.f;
+                }
+                f32x4 xh = (py[(size_t)r * ld] - mu) * is;
+                sb += gv; sg += gv * xh;
+            }
+        }
+        red[0][tid] = sb; red[1][tid] = sg;
+        __syncthreads();
+        if (colok && rl == 0) {
+            for (int k = 1; k < sp.RL; ++k) { sb += red[0][k * sp.CV + cv]; sg += red[1][k * sp.CV + cv]; }
+            reinterpret_cast<f32x4*>(pdb + (size_t)blockIdx.x * C)[c4] = sb;
+            reinterpret_cast<f32x4*>(pdg + (size_t)blockIdx.x * C)[c4] = sg;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_bn_bwd_final(const float* __restrict__ pdb, const float* __restrict__ pdg, int P, int M,
+                                                    int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                    float* __restrict__ c1, float* __restrict__ c2) {
+    __shared__ float red[2][8][32];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float ab = 0.f, ag = 0.f;
+    if (c < C)
+        for (int b = pl; b < P; b += 8) { ab += pdb[(size_t)b * C + c]; ag += pdg[(size_t)b * C + c]; }
+    red[0][pl][cl] = ab; red[1][pl][cl] = ag;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        float sb = 0.f, sg = 0.f;
+        for (int k = 0; k < 8; ++k) { sb += red[0][k][cl]; sg += red[1][k][cl]; }
+        dbeta[c] = sb; dgamma[c] = sg;
+        c1[c] = sb / (float)M; c2[c] = sg / (float)M;
+    }
+}
+
+// dy = gamma*invstd * ( g - c1 - xhat*c2 ) ; optionally also emits g (the masked upstream gradient) for the skip path
+template <bool MASK, bool EMITG>
+__global__ __launch_bounds__(NT) void k_bn_bwd_apply(const f32x4* dA /* may alias dy */, const f32x4* __restrict__ act,
+                                                    const f32x4* __restrict__ y, const f32x4* __restrict__ mean,
+                                                    const f32x4* __restrict__ invstd, const f32x4* __restrict__ gamma,
+                                                    const f32x4* __restrict__ c1, const f32x4* __restrict__ c2,
+                                                    f32x4* dy, f32x4* __restrict__ gout, size_t n4, int c4n) {
+    size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * NT;
+    for (; i < n4; i += step) {
+        int c4 = (int)(i % (size_t)c4n);
+        f32x4 gv = dA[i];
+        if (MASK) {
+            f32x4 a = act[i];
+            gv.x = a.x > 0.f ? gv.x : 0.f; gv.y = a.y > 0.f ? gv.y : 0.f;
+            gv.z = a.z > 0.f ? gv.z : 0.f; gv.w = a.w > 0.f ? gv.w : 0.f;
+        }
+        f32x4 is = invstd[c4];
+        f32x4 xh = (y[i] - mean[c4]) * is;
+        f32x4 r = (gv - c1[c4] - xh * c2[c4]) * (gamma[c4] * is);
+        if (EMITG) gout[i] = gv;
+        dy[i] = r;
+    }
+}
+
+static int rows_per_block(int M, int C, int& P) {
+    // ~256 KiB of activations per workgroup, at most 1024 workgroups
+    long rows = (256l * 1024) / ((long)C * 4);
+    if (rows < 8) rows = 8;
+    long minrows = (M + 1023) / 1024;
+    if (rows < minrows) rows = minrows;
+    if (rows > M) rows = M;
+    P = (int)((M + rows - 1) / rows);
+    return (int)rows;
+}
+static int stream_grid(size_t n4) {
+    size_t g = (n4 + NT - 1) / NT;
+    return (int)(g > 2048 ? 2048 : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t osi_bn_workspace(int M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    int P;
+    rows_per_block(M, C, P);
+    return (size_t)2 * P * C * sizeof(float);
+}
+
+int osi_bn_train_stats(const float* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                       void* ws, size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(y && gamma && beta && mean && invstd && scale && shift && ws);
+    OSI_REQUIRE(M > 0 && C > 0 && C % 4 == 0);
+    OSI_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    int P;
+    int rpb = rows_per_block(M, C, P);
+    OSI_REQUIRE(ws_bytes >= (size_t)2 * P * C * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float* pmean = (float*)ws;
+    float* pm2 = pmean + (size_t)P * C;
+    hipLaunchKernelGGL(k_bn_stats_partial, dim3(P), dim3(NT), 0, st, y, M, C, rpb, pmean, pm2);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_stats_final, dim3(osi_cdiv(C, 32)), dim3(NT), 0, st, pmean, pm2, P, rpb, M, C, gamma, beta, eps,
+                       momentum, running_mean, running_var, mean, invstd, scale, shift);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+int osi_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
+                       int C, float* scale, float* shift, osi_stream_t stream) {
+    OSI_REQUIRE(running_mean && running_var && gamma && beta && scale && shift && C > 0);
+    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(osi_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean, running_var,
+                       gamma, beta, eps, C, scale, shift);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+int osi_bn_apply(const float* y, const float* residual, const float* scale, const float* shift, float* out, int M, int C,
+                 int relu, osi_stream_t stream) {
+    OSI_REQUIRE(y && scale && shift && out && M > 0 && C > 0 && C % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n4 = (size_t)M * C / 4;
+    const int grid = stream_grid(n4), c4n = C / 4;
+    auto Y = (const f32x4*)y; auto R = (const f32x4*)residual; auto S = (const f32x4*)scale; auto H = (const f32x4*)shift;
+    auto O = (f32x4*)out;
+    if (residual && relu) hipLaunchKernelGGL((k_bn_apply<true, true>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, n4, c4n);
+    else if (residual) hipLaunchKernelGGL((k_bn_apply<true, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, n4, c4n);
+    else if (relu) hipLaunchKernelGGL((k_bn_apply<false, true>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, n4, c4n);
+    else hipLaunchKernelGGL((k_bn_apply<false, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, n4, c4n);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+int osi_bn_backward(const float* dout, const float* act, const float* y, const float* mean, const float* invstd,
+                    const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
+                    size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(dout && y && mean && invstd && gamma && dy && dgamma && dbeta && ws);
+    OSI_REQUIRE(M > 0 && C > 0 && C % 4 == 0);
+    OSI_REQUIRE(!(gmasked && !act) || true);
+    int P;
+    int rpb = rows_per_block(M, C, P);
+    // partial sums + the two per-channel coefficient vectors
+    OSI_REQUIRE(ws_bytes >= ((size_t)2 * P * C + 2 * (size_t)C) * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float* pdb = (float*)ws;
+    float* pdg = pdb + (size_t)P * C;
+    float* c1 = pdg + (size_t)P * C;
+    float* c2 = c1 + C;
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(P), dim3(NT), 0, st, dout, act, y, mean, invstd, M, C, rpb, pdb, pdg);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, 32)), dim3(NT), 0, st, pdb, pdg, P, M, C, dgamma, dbeta, c1, c2);
+    OSI_LAUNCH_CHECK();
+    const size_t n4 = (size_t)M * C / 4;
+    const int grid = stream_grid(n4), c4n = C / 4;
+    auto D = (const f32x4*)dout; auto A = (const f32x4*)act; auto Y = (const f32x4*)y;
+    auto MU = (const f32x4*)mean; auto IS = (const f32x4*)invstd; auto G = (const f32x4*)gamma;
+    auto C1 = (const f32x4*)c1; auto C2 = (const f32x4*)c2;
+    auto DY = (f32x4*)dy; auto GO = (f32x4*)gmasked;
+    if (act && gmasked) hipLaunchKernelGGL((k_bn_bwd_apply<true, true>), dim3(grid), dim3(NT), 0, st, D, A, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n);
+    else if (act) hipLaunchKernelGGL((k_bn_bwd_apply<true, false>), dim3(grid), dim3(NT), 0, st, D, A, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n);
+    else if (gmasked) hipLaunchKernelGGL((k_bn_bwd_apply<false, true>), dim3(grid), dim3(NT), 0, st, D, A, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n);
+    else hipLaunchKernelGGL((k_bn_bwd_apply<false, false>), dim3(grid), dim3(NT), 0, st, D, A, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+size_t osi_bn_backward_workspace(int M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    int P;
+    rows_per_block(M, C, P);
+    return ((size_t)2 * P * C + 2 * (size_t)C) * sizeof(float);
+}
+
+}  // extern "C"

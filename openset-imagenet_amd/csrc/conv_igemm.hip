@@ -1,0 +1,696 @@
+// Implicit-GEMM convolutions on the exact-fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the 53 bias-free conv2d forward / input-gradient / weight-gradient calls that
+// torchvision's ResNet-50 issues under openset_imagenet/model.py:17,37 (reference) — see
+// SURVEY.md Appendix A for the 23 unique shapes.
+//
+// Data layout (all fp32):
+//   activations  NHWC   [B][H][W][C]            (C contiguous -> the GEMM K axis of fwd/dgrad is contiguous)
+//   weights      KRSC   [Cout][R][S][Cin]       (= torch OIHW tensor in channels_last strides)
+//
+// GEMM views
+//   fwd    Y[m, n]  = sum_k  im2col(X)[m, k] * W[n, k]          m=(b,ho,wo)  k=(r,s,c)  n=cout
+//   dgrad  dX[m, c] = sum_k  im2col'(dY)[m, k] * W[(n), (r,s), c] m=(b,h,w)   k=(r,s,n)
+//   wgrad  dW[n, (r,s,c)] = sum_m dY[m, n] * im2col(X)[m, (r,s,c)]            k=m (split across blocks)
+//
+// One workgroup = 4 waves in a 2x2 grid; each wave owns WM x WN MFMA tiles of 32x32, K-step 32 per
+// LDS stage, two LDS stages, register-staged global->LDS copies (the im2col gather and zero padding
+// happen in registers), one barrier per K tile.
+//
+// LDS operand images
+//   "R" image  [rows][32 + 4]  k contiguous, read with ds_read_b128 (conflict-free at a 36-float row stride)
+//   "C" image  [32][cols]      k major, read with ds_read_b32 (lanes walk 32 consecutive floats)
+// The K order inside a stage is permuted identically for both operands (lane half h of MFMA (j,e) consumes
+// k = 8j + 4h + e), which a dot product does not care about.
+#include "osi_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDR = BK + 4;  // row stride of an "R" image, floats
+
+struct ConvP {
+    const float* x;   // fwd: input, dgrad: dY, wgrad: X
+    const float* w;   // fwd/dgrad: weights, wgrad: dY
+    float* y;         // fwd: Y, dgrad: dX, wgrad: dW or slab
+    int B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+    int M;            // GEMM M (fwd: B*Ho*Wo)
+    int Ktot;         // R*S*Cin (row length of W)
+    int MT, NT;       // tile counts
+    int accumulate;   // epilogue adds into y
+    FastDiv dHoWo, dWo;  // fwd/wgrad: divide by Ho*Wo, Wo ; dgrad: by Hc*Wc, Wc of the class grid
+    // wgrad only
+    int kchunk;       // pixels per split
+    size_t slab_stride;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// XCD-aware tile mapping: workgroups b and b+8 share an XCD (and its L2). All NT column tiles of one row
+// tile are placed on one XCD in consecutive dispatch slots, so the im2col rows are fetched from HBM once.
+__device__ __forceinline__ bool tile_of_block(int bid, int MT, int NT, int& mt, int& nt) {
+    int xcd = bid & 7, slot = bid >> 3;
+    nt = slot % NT;
+    mt = (slot / NT) * 8 + xcd;
+    return mt < MT;
+}
+
+// ---- MFMA over one LDS stage -------------------------------------------------------------------------
+// A: R image (rows = GEMM rows), B: R image (rows = GEMM cols)
+template <int WM, int WN>
+__device__ __forceinline__ void mma_RR(const float* sA, const float* sB, int arow, int brow, int lane,
+                                       f32x16 (&acc)[WM][WN]) {
+    const int h4 = (lane >> 5) * 4, l31 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 a[WM], b[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const f32x4*>(sA + (arow + i * 32 + l31) * LDR + 8 * j + h4);
+#pragma unroll
+        for (int i = 0; i < WN; ++i) b[i] = *reinterpret_cast<const f32x4*>(sB + (brow + i * 32 + l31) * LDR + 8 * j + h4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[n][e], acc[i][n], 0, 0, 0);
+    }
+}
+// A: R image, B: C image [32][LDC]
+template <int WM, int WN, int LDC>
+__device__ __forceinline__ void mma_RC(const float* sA, const float* sB, int arow, int bcol, int lane,
+                                       f32x16 (&acc)[WM][WN]) {
+    const int h4 = (lane >> 5) * 4, l31 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 a[WM];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const f32x4*>(sA + (arow + i * 32 + l31) * LDR + 8 * j + h4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float b[WN];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) b[n] = sB[(8 * j + h4 + e) * LDC + bcol + n * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[n], acc[i][n], 0, 0, 0);
+        }
+    }
+}
+// A: C image [32][LDA], B: C image [32][LDB]
+template <int WM, int WN, int LDA, int LDB>
+__device__ __forceinline__ void mma_CC(const float* sA, const float* sB, int acol, int bcol, int lane,
+                                       f32x16 (&acc)[WM][WN]) {
+    const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+        float a[WM], b[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = sA[(2 * ks + h) * LDA + acol + i * 32 + l31];
+#pragma unroll
+        for (int n = 0; n < WN; ++n) b[n] = sB[(2 * ks + h) * LDB + bcol + n * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[n], acc[i][n], 0, 0, 0);
+    }
+}
+
+// Accumulator element (reg r of lane) -> row inside the 32x32 tile. Column = lane & 31.
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ======================================================================================================
+// Forward
+// ======================================================================================================
+template <int WM, int WN, bool STEM>
+__global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int AR = BM / 32, BR = BN / 32;  // float4 loads per thread per stage
+    constexpr int STAGE = (BM + BN) * LDR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    int mt, nt;
+    if (!tile_of_block(blockIdx.x, p.MT, p.NT, mt, nt)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kq = tid & 7, lr = tid >> 3;  // float4 slot inside a 32-float row, row inside a 32-row pass
+
+    // per-thread im2col rows
+    int a_base[AR], a_h0[AR], a_w0[AR];
+    bool a_ok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        int m = m0 + lr + 32 * i;
+        a_ok[i] = m < p.M;
+        uint32_t mm = a_ok[i] ? (uint32_t)m : 0u;
+        uint32_t b = fdiv(mm, p.dHoWo);
+        uint32_t rem = mm - b * p.dHoWo.d;
+        uint32_t ho = fdiv(rem, p.dWo);
+        uint32_t wo = rem - ho * p.dWo.d;
+        a_base[i] = (int)b * p.H * p.W * p.Cin;
+        a_h0[i] = (int)ho * p.stride - p.pad;
+        a_w0[i] = (int)wo * p.stride - p.pad;
+    }
+    const float* wrow = p.w + (size_t)(n0 + lr) * p.Ktot + kq * 4;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+
+    const int T = p.Ktot / BK;
+    int r = 0, s = 0, c0 = 0;  // current tap / channel offset (non-stem)
+    f32x4 ra[AR], rb[BR];
+
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            int hi, wi, coff;
+            bool ok = a_ok[i];
+            if (STEM) {
+                int tap = t * 8 + kq;  // Cin = 4: one tap per float4
+                int rr = tap / 7, ss = tap - rr * 7;
+                hi = a_h0[i] + rr; wi = a_w0[i] + ss; coff = 0;
+                ok = ok && tap < 49;
+            } else {
+                hi = a_h0[i] + r; wi = a_w0[i] + s; coff = c0 + kq * 4;
+            }
+            ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            int off = ok ? a_base[i] + (hi * p.W + wi) * p.Cin + coff : 0;
+            f32x4 v = ld4(p.x + off);
+            ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) rb[i] = ld4(wrow + (size_t)(32 * i) * p.Ktot + t * BK);
+    };
+    auto advance = [&]() {
+        if (!STEM) {
+            c0 += BK;
+            if (c0 == p.Cin) { c0 = 0; if (++s == p.S) { s = 0; ++r; } }
+        }
+    };
+    auto sstore = [&](int buf) {
+        float* sA = smem + buf * STAGE;
+        float* sB = sA + BM * LDR;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(sB + (lr + 32 * i) * LDR + kq * 4) = rb[i];
+    };
+
+    gload(0); advance();
+    sstore(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) { gload(t + 1); advance(); }
+        const float* sA = smem + buf * STAGE;
+        mma_RR<WM, WN>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
+        if (t + 1 < T) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: 32 lanes of a half-wave write 128 contiguous bytes of one output row
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int col = n0 + wn * 32 * WN + n * 32 + (lane & 31);
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                int m = m0 + wm * 32 * WM + i * 32 + acc_row(rr, lane);
+                if (m < p.M) {
+                    float* dst = p.y + (size_t)m * p.Cout + col;
+                    *dst = p.accumulate ? *dst + acc[i][n][rr] : acc[i][n][rr];
+                }
+            }
+        }
+}
+
+// ======================================================================================================
+// Input gradient. Stride-s convolutions are decomposed into s*s parity classes of input pixels; each
+// class only visits the filter taps that can reach it, so no MFMA work is spent on structural zeros.
+// blockIdx.y = class. GEMM N = Cin, K = (taps of the class) x Cout.
+// ======================================================================================================
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int AR = BM / 32;
+    constexpr int LDC = BN + 4;
+    constexpr int BV = BN / 4;            // float4 per k-row of the weight tile
+    constexpr int BRP = 256 / BV;         // k-rows covered per pass
+    constexpr int BRN = BK / BRP;         // passes
+    constexpr int STAGE = BM * LDR + BK * LDC;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    int mt, nt;
+    if (!tile_of_block(blockIdx.x, p.MT, p.NT, mt, nt)) return;
+    const int st = p.stride;
+    const int cls = blockIdx.y, ph = cls / st, pw = cls - ph * st;
+    // class grid: pixels h = ph + st*h2 < H
+    const int Hc = (p.H - ph + st - 1) / st, Wc = (p.W - pw + st - 1) / st;
+    const int Mc = p.B * Hc * Wc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = mt * BM, n0 = nt * BN;
+    if (m0 >= Mc) return;
+    const int kq = tid & 7, lr = tid >> 3;
+
+    // taps reaching this class: r = rb + st*jr, (h + pad - r) / st = hb - jr
+    const int rb = (ph + p.pad) % st, sb = (pw + p.pad) % st;
+    const int nR = rb < p.R ? (p.R - rb + st - 1) / st : 0;
+    const int nS = sb < p.S ? (p.S - sb + st - 1) / st : 0;
+
+    int a_base[AR], a_hb[AR], a_wb[AR];
+    bool a_ok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        int m = m0 + lr + 32 * i;
+        a_ok[i] = m < Mc;
+        int mm = a_ok[i] ? m : 0;
+        int b = mm / (Hc * Wc);
+        int rem = mm - b * Hc * Wc;
+        int h2 = rem / Wc, w2 = rem - h2 * Wc;
+        a_base[i] = b * p.Ho * p.Wo * p.Cout;
+        a_hb[i] = (ph + st * h2 + p.pad - rb) / st;
+        a_wb[i] = (pw + st * w2 + p.pad - sb) / st;
+    }
+    (void)Hc0; (void)Wc0;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+
+    const int KC = p.Cout / BK;          // K tiles per tap
+    const int T = nR * nS * KC;
+    int jr = 0, js = 0, c0 = 0;
+    f32x4 ra[AR], rbv[BRN];
+    const int bk_row = tid / BV, bk_col = (tid % BV) * 4;
+
+    auto gload = [&]() {
+        const int r = rb + st * jr, s = sb + st * js;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            int ho = a_hb[i] - jr, wo = a_wb[i] - js;
+            bool ok = a_ok[i] && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
+            int off = ok ? a_base[i] + (ho * p.Wo + wo) * p.Cout + c0 + kq * 4 : 0;
+            f32x4 v = ld4(p.x + off);
+            ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // weight tile: rows k = cout c0..c0+31, cols = cin n0..n0+BN-1 at tap (r,s)
+#pragma unroll
+        for (int i = 0; i < BRN; ++i) {
+            int kk = bk_row + BRP * i;
+            rbv[i] = ld4(p.w + (size_t)(c0 + kk) * p.Ktot + (r * p.S + s) * p.Cin + n0 + bk_col);
+        }
+    };
+    auto advance = [&]() {
+        c0 += BK;
+        if (c0 == p.Cout) { c0 = 0; if (++js == nS) { js = 0; ++jr; } }
+    };
+    auto sstore = [&](int buf) {
+        float* sA = smem + buf * STAGE;
+        float* sB = sA + BM * LDR;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (bk_row + BRP * i) * LDC + bk_col) = rbv[i];
+    };
+
+    if (T > 0) {
+        gload(); advance();
+        sstore(0);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < T) { gload(); advance(); }
+            const float* sA = smem + buf * STAGE;
+            mma_RC<WM, WN, LDC>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
+            if (t + 1 < T) sstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            int m = m0 + wm * 32 * WM + i * 32 + acc_row(rr, lane);
+            if (m < Mc) {
+                int b = m / (Hc * Wc);
+                int rem = m - b * Hc * Wc;
+                int h2 = rem / Wc, w2 = rem - h2 * Wc;
+                size_t pix = ((size_t)b * p.H + (ph + st * h2)) * p.W + (pw + st * w2);
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    const int col = n0 + wn * 32 * WN + n * 32 + (lane & 31);
+                    float* dst = p.y + pix * p.Cin + col;
+                    *dst = p.accumulate ? *dst + acc[i][n][rr] : acc[i][n][rr];
+                }
+            }
+        }
+}
+
+// ======================================================================================================
+// Weight gradient. GEMM rows = cout, cols = (tap, cin range), K = pixels. blockIdx.y = K split.
+// STEM: Cin = 4 (padded RGB), 56 padded taps -> 224 columns, a column tile spans 16 taps.
+// ======================================================================================================
+template <int WM, int WN, bool STEM>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(ConvP p) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int AV = BM / 4, ARP = 256 / AV, ARN = BK / ARP;
+    constexpr int BV = BN / 4, BRP = 256 / BV, BRN = BK / BRP;
+    constexpr int STAGE = BK * (LDA + LDB);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // tiles: rows over cout (MT), cols over (tap, cin tile) (NT)
+    const int bid = blockIdx.x;
+    const int mt = bid % p.MT, ntile = bid / p.MT;
+    const int n0 = mt * BM;  // cout offset
+    int tap = 0, c0 = 0, r = 0, s = 0;
+    if (!STEM) {
+        const int ctiles = p.Cin / BN;
+        tap = ntile / ctiles; c0 = (ntile - tap * ctiles) * BN;
+        r = tap / p.S; s = tap - r * p.S;
+    }
+    const int kbeg = blockIdx.y * p.kchunk;
+    const int kend = min(p.M, kbeg + p.kchunk);
+    const int T = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) acc[i][n][rr] = 0.f;
+
+    const int a_row = tid / AV, a_col = (tid % AV) * 4;
+    const int b_row = tid / BV, b_col = (tid % BV) * 4;
+    f32x4 ra[ARN], rbv[BRN];
+
+    auto gload = [&](int t) {
+        const int kb = kbeg + t * BK;
+#pragma unroll
+        for (int i = 0; i < ARN; ++i) {
+            int m = kb + a_row + ARP * i;
+            bool ok = m < kend;
+            f32x4 v = ld4(p.w + (size_t)(ok ? m : 0) * p.Cout + n0 + a_col);
+            ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < BRN; ++i) {
+            int m = kb + b_row + BRP * i;
+            bool ok = m < kend;
+            uint32_t mm = ok ? (uint32_t)m : 0u;
+            uint32_t b = fdiv(mm, p.dHoWo);
+            uint32_t rem = mm - b * p.dHoWo.d;
+            uint32_t ho = fdiv(rem, p.dWo);
+            uint32_t wo = rem - ho * p.dWo.d;
+            int rr = r, ss = s, coff = c0 + b_col;
+            if (STEM) {
+                int tp = ntile * (BN / 4) + (b_col >> 2);
+                rr = tp / 7; ss = tp - rr * 7; coff = 0;
+                ok = ok && tp < 49;
+            }
+            int hi = (int)ho * p.stride - p.pad + rr, wi = (int)wo * p.stride - p.pad + ss;
+            ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            int off = ok ? (((int)b * p.H + hi) * p.W + wi) * p.Cin + coff : 0;
+            f32x4 v = ld4(p.x + off);
+            rbv[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto sstore = [&](int buf) {
+        float* sA = smem + buf * STAGE;
+        float* sB = sA + BK * LDA;
+#pragma unroll
+        for (int i = 0; i < ARN; ++i) *reinterpret_cast<f32x4*>(sA + (a_row + ARP * i) * LDA + a_col) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (b_row + BRP * i) * LDB + b_col) = rbv[i];
+    };
+
+    if (T > 0) {
+        gload(0);
+        sstore(0);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < T) gload(t + 1);
+            const float* sA = smem + buf * STAGE;
+            mma_CC<WM, WN, LDA, LDB>(sA, sA + BK * LDA, wm * 32 * WM, wn * 32 * WN, lane, acc);
+            if (t + 1 < T) sstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    float* out = p.y + (size_t)blockIdx.y * p.slab_stride;
+    const int colbase = STEM ? ntile * BN : tap * p.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int col = colbase + wn * 32 * WN + n * 32 + (lane & 31);
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                int row = n0 + wm * 32 * WM + i * 32 + acc_row(rr, lane);
+                if (col < p.Ktot) out[(size_t)row * p.Ktot + col] = acc[i][n][rr];
+            }
+        }
+}
+
+// out[i] = sum_s slab[s][i]  (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(256) void k_slab_reduce(const float* slab, float* out, size_t n4, size_t stride4, int splits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    const f32x4* s = reinterpret_cast<const f32x4*>(slab);
+    for (; i < n4; i += step) {
+        f32x4 a = s[i];
+        for (int k = 1; k < splits; ++k) a += s[i + k * stride4];
+        reinterpret_cast<f32x4*>(out)[i] = a;
+    }
+}
+
+// stem weight [64][7][7][3] (KRSC of the OIHW parameter) <-> packed [64][56][4] (zero padded taps/channel)
+__global__ void k_stem_pack(const float* w, float* wp, int Cout) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * 224) return;
+    int n = i / 224, k = i - n * 224, tap = k >> 2, c = k & 3;
+    wp[i] = (tap < 49 && c < 3) ? w[(n * 49 + tap) * 3 + c] : 0.f;
+}
+__global__ void k_stem_unpack(const float* gp, float* g, int Cout) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * 147) return;
+    int n = i / 147, k = i - n * 147, tap = k / 3, c = k - tap * 3;
+    g[i] = gp[n * 224 + tap * 4 + c];
+}
+
+template <typename K>
+static int set_smem(K kern, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+            return OSI_ERR_LAUNCH;
+    }
+    return OSI_OK;
+}
+
+static bool desc_ok(const osi_conv_desc* d) {
+    if (!d) return false;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return false;
+    if (d->R <= 0 || d->S <= 0 || d->stride <= 0 || d->pad < 0) return false;
+    if (d->Ho != (d->H + 2 * d->pad - d->R) / d->stride + 1) return false;
+    if (d->Wo != (d->W + 2 * d->pad - d->S) / d->stride + 1) return false;
+    if (d->Ho <= 0 || d->Wo <= 0) return false;
+    // 31-bit element offsets
+    if ((long)d->B * d->H * d->W * d->Cin >= (1l << 31)) return false;
+    if ((long)d->B * d->Ho * d->Wo * d->Cout >= (1l << 31)) return false;
+    return true;
+}
+static bool is_stem(const osi_conv_desc* d) { return d->Cin == 4 && d->R == 7 && d->S == 7; }
+
+static ConvP make_p(const osi_conv_desc* d) {
+    ConvP p{};
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
+    p.M = d->B * d->Ho * d->Wo;
+    p.Ktot = is_stem(d) ? 224 : d->R * d->S * d->Cin;
+    p.dHoWo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
+    p.dWo = make_fastdiv((uint32_t)d->Wo);
+    return p;
+}
+
+template <int WM, int WN, bool STEM>
+static int launch_fwd(ConvP p, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    p.MT = osi_cdiv(p.M, BM); p.NT = p.Cout / BN;
+    size_t smem = 2 * (size_t)(BM + BN) * LDR * sizeof(float);
+    if (int e = set_smem(k_conv_fwd<WM, WN, STEM>, smem)) return e;
+    int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
+    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM>), dim3(grid), dim3(256), smem, st, p);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+template <int WM, int WN>
+static int launch_dgrad(ConvP p, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int s = p.stride;
+    const int Hc = osi_cdiv(p.H, s), Wc = osi_cdiv(p.W, s);  // largest class
+    p.MT = osi_cdiv((long)p.B * Hc * Wc, BM); p.NT = p.Cin / BN;
+    size_t smem = 2 * (size_t)(BM * LDR + BK * (BN + 4)) * sizeof(float);
+    if (int e = set_smem(k_conv_dgrad<WM, WN>, smem)) return e;
+    int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
+    hipLaunchKernelGGL((k_conv_dgrad<WM, WN>), dim3(grid, s * s), dim3(256), smem, st, p, Hc, Wc);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+template <int WM, int WN, bool STEM>
+static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    p.MT = p.Cout / BM;
+    p.NT = STEM ? osi_cdiv(p.Ktot, BN) : p.R * p.S * (p.Cin / BN);
+    size_t smem = 2 * (size_t)BK * (BM + 4 + BN + 4) * sizeof(float);
+    if (int e = set_smem(k_conv_wgrad<WM, WN, STEM>, smem)) return e;
+    hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM>), dim3(p.MT * p.NT, splits), dim3(256), smem, st, p);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+// wgrad geometry shared by the workspace query and the launcher
+struct WgradPlan { int wm, wn, splits, kchunk; };
+static WgradPlan plan_wgrad(const osi_conv_desc* d) {
+    WgradPlan w;
+    const bool stem = is_stem(d);
+    w.wm = (d->Cout % 128 == 0) ? 2 : 1;
+    w.wn = (!stem && d->Cin % 128 == 0) ? 2 : 1;
+    const int BMg = 64 * w.wm, BNg = 64 * w.wn;
+    const int Ktot = stem ? 224 : d->R * d->S * d->Cin;
+    const long tiles = (long)(d->Cout / BMg) * (stem ? osi_cdiv(Ktot, BNg) : d->R * d->S * (d->Cin / BNg));
+    const long M = (long)d->B * d->Ho * d->Wo;
+    long splits = (1024 + tiles - 1) / tiles;               // aim at ~4 workgroups per CU
+    long maxs = (M + 4 * BK - 1) / (4 * BK);                // at least 4 K tiles per split
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    long chunk = ((M + splits - 1) / splits + BK - 1) / BK * BK;
+    splits = (M + chunk - 1) / chunk;
+    w.splits = (int)splits; w.kchunk = (int)chunk;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int osi_conv_fwd(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, osi_stream_t stream) {
+    OSI_REQUIRE(desc_ok(d) && x && w && y);
+    hipStream_t st = (hipStream_t)stream;
+    ConvP p = make_p(d);
+    p.x = x; p.w = w; p.y = y; p.accumulate = 0;
+    if (is_stem(d)) {
+        OSI_REQUIRE(d->Cout % 64 == 0 && d->stride >= 1);
+        return launch_fwd<2, 1, true>(p, st);
+    }
+    OSI_REQUIRE(d->Cin % BK == 0 && d->Cout % 64 == 0);
+    if (tile == OSI_TILE_AUTO) {
+        const long M = p.M;
+        if (d->Cout % 128 == 0 && (M / 128) * (d->Cout / 128) >= 384) tile = OSI_TILE_128x128;
+        else if ((M / 128) * (d->Cout / 64) >= 384) tile = OSI_TILE_128x64;
+        else if (d->Cout % 128 == 0 && (M / 64) * (d->Cout / 128) >= 256) tile = OSI_TILE_64x128;
+        else tile = OSI_TILE_64x64;
+    }
+    switch (tile) {
+        case OSI_TILE_128x128: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<2, 2, false>(p, st);
+        case OSI_TILE_128x64: return launch_fwd<2, 1, false>(p, st);
+        case OSI_TILE_64x128: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<1, 2, false>(p, st);
+        case OSI_TILE_64x64: return launch_fwd<1, 1, false>(p, st);
+        default: return OSI_ERR_ARG;
+    }
+}
+
+int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, int tile,
+                   osi_stream_t stream) {
+    OSI_REQUIRE(desc_ok(d) && dy && w && dx);
+    OSI_REQUIRE(!is_stem(d));  // the image needs no gradient (train.py:128-139: input is a leaf without grad)
+    OSI_REQUIRE(d->Cout % BK == 0 && d->Cin % 64 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    ConvP p = make_p(d);
+    p.x = dy; p.w = w; p.y = dx; p.accumulate = accumulate;
+    if (tile == OSI_TILE_AUTO) {
+        const long M = (long)d->B * d->H * d->W;
+        if (d->Cin % 128 == 0 && (M / 128) * (d->Cin / 128) >= 384) tile = OSI_TILE_128x128;
+        else if ((M / 128) * (d->Cin / 64) >= 384) tile = OSI_TILE_128x64;
+        else if (d->Cin % 128 == 0 && (M / 64) * (d->Cin / 128) >= 256) tile = OSI_TILE_64x128;
+        else tile = OSI_TILE_64x64;
+    }
+    switch (tile) {
+        case OSI_TILE_128x128: OSI_REQUIRE(d->Cin % 128 == 0); return launch_dgrad<2, 2>(p, st);
+        case OSI_TILE_128x64: return launch_dgrad<2, 1>(p, st);
+        case OSI_TILE_64x128: OSI_REQUIRE(d->Cin % 128 == 0); return launch_dgrad<1, 2>(p, st);
+        case OSI_TILE_64x64: return launch_dgrad<1, 1>(p, st);
+        default: return OSI_ERR_ARG;
+    }
+}
+
+size_t osi_conv_wgrad_workspace(const osi_conv_desc* d) {
+    if (!desc_ok(d)) return 0;
+    WgradPlan w = plan_wgrad(d);
+    const size_t n = (size_t)d->Cout * (is_stem(d) ? 224 : d->R * d->S * d->Cin);
+    return w.splits > 1 ? (size_t)w.splits * n * sizeof(float) : 0;
+}
+
+int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, float* dw, void* ws, size_t ws_bytes,
+                   osi_stream_t stream) {
+    OSI_REQUIRE(desc_ok(d) && dy && x && dw);
+    const bool stem = is_stem(d);
+    OSI_REQUIRE(d->Cout % 64 == 0 && (stem || d->Cin % 64 == 0));
+    hipStream_t st = (hipStream_t)stream;
+    WgradPlan w = plan_wgrad(d);
+    ConvP p = make_p(d);
+    const size_t n = (size_t)d->Cout * p.Ktot;
+    OSI_REQUIRE(n % 4 == 0);
+    if (w.splits > 1) OSI_REQUIRE(ws && ws_bytes >= (size_t)w.splits * n * sizeof(float));
+    p.x = x; p.w = dy; p.y = w.splits > 1 ? (float*)ws : dw;
+    p.kchunk = w.kchunk; p.slab_stride = n;
+    int e;
+    if (stem) e = launch_wgrad<1, 1, true>(p, w.splits, st);
+    else if (w.wm == 2 && w.wn == 2) e = launch_wgrad<2, 2, false>(p, w.splits, st);
+    else if (w.wm == 2) e = launch_wgrad<2, 1, false>(p, w.splits, st);
+    else if (w.wn == 2) e = launch_wgrad<1, 2, false>(p, w.splits, st);
+    else e = launch_wgrad<1, 1, false>(p, w.splits, st);
+    if (e) return e;
+    if (w.splits > 1) {
+        size_t n4 = n / 4;
+        int grid = (int)((n4 + 255) / 256); if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(k_slab_reduce, dim3(grid), dim3(256), 0, st, (const float*)ws, dw, n4, n4, w.splits);
+        OSI_LAUNCH_CHECK();
+    }
+    return OSI_OK;
+}
+
+int osi_stem_weight_pack(const float* w_krsc3, float* w_packed, int Cout, osi_stream_t stream) {
+    OSI_REQUIRE(w_krsc3 && w_packed && Cout > 0);
+    hipLaunchKernelGGL(k_stem_pack, dim3(osi_cdiv(Cout * 224, 256)), dim3(256), 0, (hipStream_t)stream, w_krsc3, w_packed, Cout);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+int osi_stem_grad_unpack(const float* g_packed, float* g_krsc3, int Cout, osi_stream_t stream) {
+    OSI_REQUIRE(g_packed && g_krsc3 && Cout > 0);
+    hipLaunchKernelGGL(k_stem_unpack, dim3(osi_cdiv(Cout * 147, 256)), dim3(256), 0, (hipStream_t)stream, g_packed, g_krsc3, Cout);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Shared device/host helpers for the gfx950 kernels of the open-set ImageNet hot path.
+// Everything here is CDNA4-only (wave64, MFMA f32 32x32x2); there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/osi.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define OSI_LAUNCH_CHECK()                                     \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) return OSI_ERR_LAUNCH;          \
+    } while (0)
+
+#define OSI_REQUIRE(cond)                                      \
+    do {                                                       \
+        if (!(cond)) return OSI_ERR_ARG;                       \
+    } while (0)
+
+static inline int osi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Unsigned division by a runtime-constant divisor: q = (n * mul) >> (32 + sh), exact for n < 2^31.
+struct FastDiv {
+    uint32_t mul, sh, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d == 1) { f.mul = 0; f.sh = 0; return f; }
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;           // l = ceil(log2 d)
+    uint64_t m = ((1ull << (32 + l)) + d - 1) / d;  // ceil(2^(32+l)/d), fits 33 bits
+    f.mul = (uint32_t)(m - (1ull << 32));  // low 32 bits; the implicit 2^32 is added back in the divide
+    f.sh = l;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    if (f.d == 1) return n;
+    uint32_t t = __umulhi(n, f.mul);
+    // q = (t + n) >> sh without overflow: ((n - t) >> 1) + t, then >> (sh-1)
+    return (((n - t) >> 1) + t) >> (f.sh - 1);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,152 @@
+// Stream kernels around the conv stack: NCHW image -> NHWC4 staging, MaxPool(3,2,1) fwd/bwd, global average
+// pool fwd/bwd. They replace torchvision ResNet.maxpool / ResNet.avgpool / torch.flatten under
+// openset_imagenet/model.py:37 (reference) and the implicit layout of the input batch (train.py:128).
+#include "osi_common.h"
+
+namespace {
+
+// [B][3][H][W] -> [B][H][W][4], 4th channel zero (the stem conv treats the image as 4-channel, K = 49*4).
+__global__ __launch_bounds__(256) void k_nchw3_to_nhwc4(const float* __restrict__ x, f32x4* __restrict__ y, int B, int HW) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)B * HW, step = (size_t)gridDim.x * 256;
+    for (; i < n; i += step) {
+        size_t b = i / HW, p = i - b * HW;
+        const float* s = x + b * 3 * HW + p;
+        y[i] = f32x4{s[0], s[HW], s[2 * (size_t)HW], 0.f};
+    }
+}
+
+// MaxPool 3x3 stride 2 pad 1, NHWC. idx = position (0..8) of the first maximum in row-major window order
+// (torch's tie rule: strictly-greater replaces), stored as one byte per output element.
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const f32x4* __restrict__ x, f32x4* __restrict__ y, uint32_t* __restrict__ idx,
+                                                    int B, int H, int W, int C4, int Ho, int Wo) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)B * Ho * Wo * C4;
+    if (i >= n) return;
+    int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    int wo = (int)(t % Wo); t /= Wo;
+    int ho = (int)(t % Ho);
+    int b = (int)(t / Ho);
+    const float NEG = -__builtin_inff();
+    f32x4 best = {NEG, NEG, NEG, NEG};
+    uint32_t bi[4] = {0, 0, 0, 0};
+    bool first[4] = {true, true, true, true};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            int h = ho * 2 - 1 + r, w = wo * 2 - 1 + s;
+            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                f32x4 v = x[((size_t)(b * H + h) * W + w) * C4 + c4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (first[k] || v[k] > best[k]) { best[k] = v[k]; bi[k] = r * 3 + s; first[k] = false; }
+            }
+        }
+    y[i] = best;
+    idx[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+}
+
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const f32x4* __restrict__ dy, const uint32_t* __restrict__ idx, f32x4* __restrict__ dx,
+                                                    int B, int H, int W, int C4, int Ho, int Wo) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)B * H * W * C4;
+    if (i >= n) return;
+    int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    int w = (int)(t % W); t /= W;
+    int h = (int)(t % H);
+    int b = (int)(t / H);
+    f32x4 acc = {0, 0, 0, 0};
+    // windows containing (h, w): ho*2-1 <= h <= ho*2+1
+    int ho_lo = h >> 1, ho_hi = (h + 1) >> 1;  // floor(h/2) .. floor((h+1)/2)
+    int wo_lo = w >> 1, wo_hi = (w + 1) >> 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+        if (ho >= Ho) continue;
+        int r = h - (ho * 2 - 1);
+        if (r < 0 || r > 2) continue;
+        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+            if (wo >= Wo) continue;
+            int s = w - (wo * 2 - 1);
+            if (s < 0 || s > 2) continue;
+            size_t o = ((size_t)(b * Ho + ho) * Wo + wo) * C4 + c4;
+            uint32_t id = idx[o];
+            f32x4 g = dy[o];
+            uint32_t me = r * 3 + s;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (((id >> (8 * k)) & 0xff) == me) acc[k] += g[k];
+        }
+    }
+    dx[i] = acc;
+}
+
+// global average pool: [B][HW][C] -> [B][C]
+__global__ __launch_bounds__(256) void k_avgpool_fwd(const f32x4* __restrict__ x, f32x4* __restrict__ y, int B, int HW, int C4) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C4) return;
+    int b = i / C4, c4 = i - b * C4;
+    f32x4 s = {0, 0, 0, 0};
+    for (int p = 0; p < HW; ++p) s += x[((size_t)b * HW + p) * C4 + c4];
+    y[i] = s / (float)HW;
+}
+__global__ __launch_bounds__(256) void k_avgpool_bwd(const f32x4* __restrict__ dy, f32x4* __restrict__ dx, int B, int HW, int C4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)B * HW * C4;
+    if (i >= n) return;
+    int c4 = (int)(i % C4);
+    int b = (int)(i / ((size_t)HW * C4));
+    dx[i] = dy[(size_t)b * C4 + c4] / (float)HW;
+}
+
+}  // namespace
+
+extern "C" {
+
+int osi_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, osi_stream_t stream) {
+    OSI_REQUIRE(x && y && B > 0 && H > 0 && W > 0);
+    size_t n = (size_t)B * H * W;
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_nchw3_to_nhwc4, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (f32x4*)y, B, H * W);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+int osi_maxpool3x3s2_fwd(const float* x, float* y, void* idx, int B, int H, int W, int C, osi_stream_t stream) {
+    OSI_REQUIRE(x && y && idx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    size_t n = (size_t)B * Ho * Wo * (C / 4);
+    OSI_REQUIRE(n < (1ul << 31));
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, (f32x4*)y,
+                       (uint32_t*)idx, B, H, W, C / 4, Ho, Wo);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+int osi_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, int B, int H, int W, int C, osi_stream_t stream) {
+    OSI_REQUIRE(dy && dx && idx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    size_t n = (size_t)B * H * W * (C / 4);
+    OSI_REQUIRE(n < (1ul << 31));
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dy,
+                       (const uint32_t*)idx, (f32x4*)dx, B, H, W, C / 4, Ho, Wo);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+int osi_avgpool_fwd(const float* x, float* y, int B, int HW, int C, osi_stream_t stream) {
+    OSI_REQUIRE(x && y && B > 0 && HW > 0 && C > 0 && C % 4 == 0);
+    hipLaunchKernelGGL(k_avgpool_fwd, dim3(osi_cdiv((long)B * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x,
+                       (f32x4*)y, B, HW, C / 4);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+int osi_avgpool_bwd(const float* dy, float* dx, int B, int HW, int C, osi_stream_t stream) {
+    OSI_REQUIRE(dy && dx && B > 0 && HW > 0 && C > 0 && C % 4 == 0);
+    size_t n = (size_t)B * HW * (C / 4);
+    hipLaunchKernelGGL(k_avgpool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dy,
+                       (f32x4*)dx, B, HW, C / 4);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,410 @@
+// Whole-network executor: one C call enqueues the complete ResNet-50 forward (or a range of backward stages)
+// of the reference model on a HIP stream — no per-layer host round trips, graph-capturable.
+//
+// Topology restated from the reference's only constructor call, openset_imagenet/model.py:17-26
+// (torchvision.models.resnet50 = ResNet v1.5: stride on the 3x3 of the first block of stages 2-4, Bottleneck
+// expansion 4, 1x1-stride-s + BN downsample on block 0 of each stage; then fc = Linear(2048, fc_dim) and
+// logits = Linear(fc_dim, out_features, bias=logit_bias)); forward = model.py:28-39; backward = the autograd
+// graph that openset_imagenet/train.py:138 (j.backward()) walks. Parameter order and names = nn.Module
+// registration order, i.e. the reference checkpoint's state_dict keys.
+#include "osi_common.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+
+#define OSI_TRY(x)                 \
+    do {                           \
+        int e__ = (x);             \
+        if (e__ != OSI_OK) return e__; \
+    } while (0)
+
+namespace {
+
+struct Tensor {
+    std::string name;
+    int ndim; int shape[4];
+    size_t off, numel;  // floats in the param arena
+};
+struct BN {
+    std::string prefix;
+    int C, M;
+    size_t g_off, b_off;    // param arena
+    size_t rm_off, rv_off;  // buffer arena
+    size_t mean, invstd, scale, shift;  // workspace (floats)
+};
+struct Conv {
+    osi_conv_desc d;
+    size_t w_off;  // param arena
+    int bn;
+    size_t y;      // workspace: conv output (pre-BN)
+    size_t a;      // workspace: BN(+res)+ReLU output (SIZE_MAX for downsample: goes to scratch)
+};
+struct Block {
+    int c1, c2, c3, ds;  // conv indices, ds = -1 if identity skip
+    size_t x_in;         // workspace offset of the block input
+    size_t out;          // = convs[c3].a
+    int stage;           // backward stage this block belongs to
+};
+
+constexpr size_t ALIGN_F = 64;  // floats (256 B)
+static size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct osi_resnet50 {
+    int B, H, W, F, O, logit_bias;
+    std::vector<Tensor> tensors;
+    std::vector<BN> bns;
+    std::vector<Conv> convs;
+    std::vector<Block> blocks;
+    size_t param_floats = 0, buffer_floats = 0, ws_floats = 0;
+    // head tensors
+    int t_fc_w, t_fc_b, t_lg_w, t_lg_b;
+    // stem
+    int Hs, Ws, Hp, Wp;              // stem conv output, maxpool output
+    size_t x4, wpack, gpack, a_pool, pool_idx, pooled, feat, logits_ws;
+    size_t bn_ws, bn_ws_bytes, wg_ws, wg_ws_bytes;
+    size_t scratch[6], scratch_floats;
+    size_t dfeat, dpooled;
+    int Hf, Wf;                      // final spatial size
+    // stage bookkeeping
+    int n_stages = 4;
+    size_t stage_lo[4], stage_hi[4];
+    // run state
+    bool fwd_done = false;
+    int next_stage = 0;
+    int cur_grad = -1;               // scratch index holding the upstream gradient between stages
+    std::vector<int> free_list;
+
+    size_t add_tensor(const std::string& name, int ndim, const int* shape) {
+        Tensor t; t.name = name; t.ndim = ndim; t.numel = 1;
+        for (int i = 0; i < 4; ++i) t.shape[i] = i < ndim ? shape[i] : 1;
+        for (int i = 0; i < ndim; ++i) t.numel *= (size_t)shape[i];
+        t.off = param_floats;
+        param_floats = up(param_floats + t.numel, 4);
+        tensors.push_back(t);
+        return t.off;
+    }
+    size_t ws_alloc(size_t floats) {
+        size_t o = ws_floats;
+        ws_floats = up(ws_floats + floats, ALIGN_F);
+        return o;
+    }
+    int add_conv_bn(const std::string& cname, const std::string& bname, int Bn, int Hin, int Win, int Cin, int Cout, int k, int s,
+                    int pad, bool keep_act) {
+        Conv c{};
+        c.d.B = Bn; c.d.H = Hin; c.d.W = Win; c.d.Cin = Cin; c.d.Cout = Cout; c.d.R = k; c.d.S = k; c.d.stride = s; c.d.pad = pad;
+        c.d.Ho = (Hin + 2 * pad - k) / s + 1; c.d.Wo = (Win + 2 * pad - k) / s + 1;
+        int shp[4] = {Cout, Cin == 4 && k == 7 ? 3 : Cin, k, k};
+        c.w_off = add_tensor(cname + ".weight", 4, shp);
+        BN b; b.prefix = bname; b.C = Cout; b.M = Bn * c.d.Ho * c.d.Wo;
+        int s1[1] = {Cout};
+        b.g_off = add_tensor(bname + ".weight", 1, s1);
+        b.b_off = add_tensor(bname + ".bias", 1, s1);
+        b.rm_off = buffer_floats; buffer_floats += up(Cout, 4);
+        b.rv_off = buffer_floats; buffer_floats += up(Cout, 4);
+        b.mean = ws_alloc(Cout); b.invstd = ws_alloc(Cout); b.scale = ws_alloc(Cout); b.shift = ws_alloc(Cout);
+        c.bn = (int)bns.size();
+        bns.push_back(b);
+        size_t n = (size_t)b.M * Cout;
+        c.y = ws_alloc(n);
+        c.a = keep_act ? ws_alloc(n) : (size_t)-1;
+        convs.push_back(c);
+        return (int)convs.size() - 1;
+    }
+    int take() {
+        if (free_list.empty()) return -1;
+        int i = free_list.back(); free_list.pop_back(); return i;
+    }
+    void give(int i) { free_list.push_back(i); }
+};
+
+extern "C" {
+
+int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, int out_features, int logit_bias) {
+    OSI_REQUIRE(out && B > 0 && H >= 32 && W >= 32 && fc_dim > 0 && out_features > 0);
+    osi_resnet50* n = new osi_resnet50();
+    n->B = B; n->H = H; n->W = W; n->F = fc_dim; n->O = out_features; n->logit_bias = logit_bias ? 1 : 0;
+    const std::string rb = "resnet_base.";
+    // stem
+    n->x4 = n->ws_alloc((size_t)B * H * W * 4);
+    n->wpack = n->ws_alloc(64 * 224);
+    n->gpack = n->ws_alloc(64 * 224);
+    int stem = n->add_conv_bn(rb + "conv1", rb + "bn1", B, H, W, 4, 64, 7, 2, 3, true);
+    n->Hs = n->convs[stem].d.Ho; n->Ws = n->convs[stem].d.Wo;
+    n->Hp = (n->Hs + 2 - 3) / 2 + 1; n->Wp = (n->Ws + 2 - 3) / 2 + 1;
+    n->a_pool = n->ws_alloc((size_t)B * n->Hp * n->Wp * 64);
+    n->pool_idx = n->ws_alloc((size_t)B * n->Hp * n->Wp * 64 / 4);
+    // stages
+    const int planes[4] = {64, 128, 256, 512}, nblk[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
+    int inpl = 64, h = n->Hp, w = n->Wp;
+    size_t x = n->a_pool;
+    for (int s = 0; s < 4; ++s) {
+        size_t lo = n->param_floats;
+        for (int b = 0; b < nblk[s]; ++b) {
+            const std::string pre = rb + "layer" + std::to_string(s + 1) + "." + std::to_string(b) + ".";
+            const int st = b == 0 ? strides[s] : 1;
+            Block blk{};
+            blk.x_in = x; blk.stage = 3 - s;
+            blk.c1 = n->add_conv_bn(pre + "conv1", pre + "bn1", B, h, w, inpl, planes[s], 1, 1, 0, true);
+            blk.c2 = n->add_conv_bn(pre + "conv2", pre + "bn2", B, h, w, planes[s], planes[s], 3, st, 1, true);
+            const int ho = n->convs[blk.c2].d.Ho, wo = n->convs[blk.c2].d.Wo;
+            blk.c3 = n->add_conv_bn(pre + "conv3", pre + "bn3", B, ho, wo, planes[s], planes[s] * 4, 1, 1, 0, true);
+            blk.ds = -1;
+            if (b == 0) blk.ds = n->add_conv_bn(pre + "downsample.0", pre + "downsample.1", B, h, w, inpl, planes[s] * 4, 1, st, 0, false);
+            blk.out = n->convs[blk.c3].a;
+            n->blocks.push_back(blk);
+            x = blk.out; inpl = planes[s] * 4; h = ho; w = wo;
+        }
+        n->stage_lo[3 - s] = lo; n->stage_hi[3 - s] = n->param_floats;
+    }
+    n->stage_lo[3] = 0;  // the stem belongs to the last backward stage
+    n->Hf = h; n->Wf = w;
+    // head
+    { int shp[2] = {fc_dim, 2048}; n->t_fc_w = (int)n->tensors.size(); n->add_tensor(rb + "fc.weight", 2, shp); }
+    { int shp[1] = {fc_dim}; n->t_fc_b = (int)n->tensors.size(); n->add_tensor(rb + "fc.bias", 1, shp); }
+    { int shp[2] = {out_features, fc_dim}; n->t_lg_w = (int)n->tensors.size(); n->add_tensor("logits.weight", 2, shp); }
+    n->t_lg_b = -1;
+    if (n->logit_bias) { int shp[1] = {out_features}; n->t_lg_b = (int)n->tensors.size(); n->add_tensor("logits.bias", 1, shp); }
+    n->stage_hi[0] = n->param_floats;  // head gradients are final after stage 0 (head + layer4)
+    n->pooled = n->ws_alloc((size_t)B * 2048);
+    n->feat = n->ws_alloc((size_t)B * fc_dim);
+    n->logits_ws = n->ws_alloc((size_t)B * out_features);
+    n->dfeat = n->ws_alloc((size_t)B * fc_dim);
+    n->dpooled = n->ws_alloc((size_t)B * 2048);
+    // scratch sizing
+    size_t maxact = 0, bnws = 0, wgws = 0;
+    for (auto& c : n->convs) {
+        size_t e = (size_t)c.d.B * c.d.Ho * c.d.Wo * c.d.Cout;
+        if (e > maxact) maxact = e;
+        size_t ein = (size_t)c.d.B * c.d.H * c.d.W * c.d.Cin;
+        if (ein > maxact) maxact = ein;
+        size_t b1 = osi_bn_workspace(n->bns[c.bn].M, c.d.Cout), b2 = osi_bn_backward_workspace(n->bns[c.bn].M, c.d.Cout);
+        if (b1 > bnws) bnws = b1;
+        if (b2 > bnws) bnws = b2;
+        size_t wg = osi_conv_wgrad_workspace(&c.d);
+        if (wg > wgws) wgws = wg;
+    }
+    n->bn_ws_bytes = bnws; n->bn_ws = n->ws_alloc(bnws / 4 + 4);
+    n->wg_ws_bytes = wgws; n->wg_ws = n->ws_alloc(wgws / 4 + 4);
+    n->scratch_floats = maxact;
+    for (int i = 0; i < 6; ++i) n->scratch[i] = n->ws_alloc(maxact);
+    *out = n;
+    return OSI_OK;
+}
+
+void osi_resnet50_destroy(osi_resnet50_t net) { delete net; }
+int osi_resnet50_num_tensors(osi_resnet50_t net) { return net ? (int)net->tensors.size() : 0; }
+size_t osi_resnet50_param_floats(osi_resnet50_t net) { return net ? net->param_floats : 0; }
+int osi_resnet50_num_bn(osi_resnet50_t net) { return net ? (int)net->bns.size() : 0; }
+size_t osi_resnet50_buffer_floats(osi_resnet50_t net) { return net ? net->buffer_floats : 0; }
+size_t osi_resnet50_workspace_bytes(osi_resnet50_t net) { return net ? net->ws_floats * sizeof(float) : 0; }
+int osi_resnet50_num_stages(osi_resnet50_t net) { return net ? net->n_stages : 0; }
+
+int osi_resnet50_tensor_info(osi_resnet50_t net, int i, char* name, int name_cap, int* ndim, int* shape, size_t* offset,
+                             size_t* numel) {
+    OSI_REQUIRE(net && i >= 0 && i < (int)net->tensors.size());
+    const Tensor& t = net->tensors[i];
+    if (name && name_cap > 0) { std::strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (ndim) *ndim = t.ndim;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = t.shape[k];
+    if (offset) *offset = t.off;
+    if (numel) *numel = t.numel;
+    return OSI_OK;
+}
+int osi_resnet50_bn_info(osi_resnet50_t net, int j, char* prefix, int cap, int* C, size_t* rm_offset, size_t* rv_offset) {
+    OSI_REQUIRE(net && j >= 0 && j < (int)net->bns.size());
+    const BN& b = net->bns[j];
+    if (prefix && cap > 0) { std::strncpy(prefix, b.prefix.c_str(), cap - 1); prefix[cap - 1] = 0; }
+    if (C) *C = b.C;
+    if (rm_offset) *rm_offset = b.rm_off;
+    if (rv_offset) *rv_offset = b.rv_off;
+    return OSI_OK;
+}
+int osi_resnet50_stage_grad_range(osi_resnet50_t net, int s, size_t* lo, size_t* hi) {
+    OSI_REQUIRE(net && s >= 0 && s < net->n_stages && lo && hi);
+    *lo = net->stage_lo[s]; *hi = net->stage_hi[s];
+    return OSI_OK;
+}
+
+static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buffers, float* ws, const float* x, const float* w,
+                       int training, hipStream_t st) {
+    Conv& c = n->convs[ci];
+    BN& b = n->bns[c.bn];
+    OSI_TRY(osi_conv_fwd(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, st));
+    if (training)
+        OSI_TRY(osi_bn_train_stats(ws + c.y, b.M, b.C, params + b.g_off, params + b.b_off, 1e-5f, 0.1f, buffers + b.rm_off,
+                                   buffers + b.rv_off, ws + b.mean, ws + b.invstd, ws + b.scale, ws + b.shift, ws + n->bn_ws,
+                                   n->bn_ws_bytes, st));
+    else
+        OSI_TRY(osi_bn_eval_coeffs(buffers + b.rm_off, buffers + b.rv_off, params + b.g_off, params + b.b_off, 1e-5f, b.C,
+                                   ws + b.scale, ws + b.shift, st));
+    return OSI_OK;
+}
+
+int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, long long* nbt, const float* image,
+                         void* workspace, float* logits, float* features, int training, osi_stream_t stream) {
+    OSI_REQUIRE(n && params && buffers && image && workspace && logits && features);
+    OSI_REQUIRE(!training || nbt);
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    n->fwd_done = false;
+    // stem
+    OSI_TRY(osi_nchw3_to_nhwc4(image, ws + n->x4, n->B, n->H, n->W, st));
+    Conv& c0 = n->convs[0];
+    OSI_TRY(osi_stem_weight_pack(params + c0.w_off, ws + n->wpack, 64, st));
+    OSI_TRY(conv_bn_fwd(n, 0, params, buffers, ws, ws + n->x4, ws + n->wpack, training, st));
+    BN& b0 = n->bns[c0.bn];
+    OSI_TRY(osi_bn_apply(ws + c0.y, nullptr, ws + b0.scale, ws + b0.shift, ws + c0.a, b0.M, 64, 1, st));
+    OSI_TRY(osi_maxpool3x3s2_fwd(ws + c0.a, ws + n->a_pool, ws + n->pool_idx, n->B, n->Hs, n->Ws, 64, st));
+    // bottleneck blocks
+    for (Block& k : n->blocks) {
+        const float* x = ws + k.x_in;
+        const int cs[3] = {k.c1, k.c2, k.c3};
+        const float* in = x;
+        for (int j = 0; j < 3; ++j) {
+            Conv& c = n->convs[cs[j]];
+            BN& b = n->bns[c.bn];
+            OSI_TRY(conv_bn_fwd(n, cs[j], params, buffers, ws, in, params + c.w_off, training, st));
+            if (j < 2) {
+                OSI_TRY(osi_bn_apply(ws + c.y, nullptr, ws + b.scale, ws + b.shift, ws + c.a, b.M, b.C, 1, st));
+                in = ws + c.a;
+            }
+        }
+        const float* res = x;
+        if (k.ds >= 0) {
+            Conv& c = n->convs[k.ds];
+            BN& b = n->bns[c.bn];
+            OSI_TRY(conv_bn_fwd(n, k.ds, params, buffers, ws, x, params + c.w_off, training, st));
+            float* xd = ws + n->scratch[0];
+            OSI_TRY(osi_bn_apply(ws + c.y, nullptr, ws + b.scale, ws + b.shift, xd, b.M, b.C, 0, st));
+            res = xd;
+        }
+        Conv& c3 = n->convs[k.c3];
+        BN& b3 = n->bns[c3.bn];
+        OSI_TRY(osi_bn_apply(ws + c3.y, res, ws + b3.scale, ws + b3.shift, ws + c3.a, b3.M, b3.C, 1, st));
+    }
+    // head
+    const float* last = ws + n->blocks.back().out;
+    OSI_TRY(osi_avgpool_fwd(last, ws + n->pooled, n->B, n->Hf * n->Wf, 2048, st));
+    const Tensor& fw = n->tensors[n->t_fc_w]; const Tensor& fb = n->tensors[n->t_fc_b]; const Tensor& lw = n->tensors[n->t_lg_w];
+    OSI_TRY(osi_linear_fwd(ws + n->pooled, params + fw.off, params + fb.off, ws + n->feat, n->B, 2048, n->F, st));
+    const float* lb = n->t_lg_b >= 0 ? params + n->tensors[n->t_lg_b].off : nullptr;
+    OSI_TRY(osi_linear_fwd(ws + n->feat, params + lw.off, lb, ws + n->logits_ws, n->B, n->F, n->O, st));
+    if (hipMemcpyAsync(features, ws + n->feat, (size_t)n->B * n->F * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return OSI_ERR_LAUNCH;
+    if (hipMemcpyAsync(logits, ws + n->logits_ws, (size_t)n->B * n->O * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return OSI_ERR_LAUNCH;
+    if (training) {
+        OSI_TRY(osi_i64_add(nbt, (int)n->bns.size(), 1, st));
+        n->fwd_done = true;
+        n->next_stage = 0;
+    }
+    return OSI_OK;
+}
+
+// backward of conv+BN(+ReLU mask): dout (in scratch `g`) -> dy in place, then wgrad; returns with dy still in `g`
+static int bn_conv_wgrad(osi_resnet50* n, int ci, const float* params, float* grads, float* ws, float* g, const float* act,
+                         float* gmasked, const float* conv_in, hipStream_t st) {
+    Conv& c = n->convs[ci];
+    BN& b = n->bns[c.bn];
+    OSI_TRY(osi_bn_backward(g, act, ws + c.y, ws + b.mean, ws + b.invstd, params + b.g_off, g, gmasked, grads + b.g_off,
+                            grads + b.b_off, b.M, b.C, ws + n->bn_ws, n->bn_ws_bytes, st));
+    if (ci == 0) {
+        OSI_TRY(osi_conv_wgrad(&c.d, g, conv_in, ws + n->gpack, ws + n->wg_ws, n->wg_ws_bytes, st));
+        OSI_TRY(osi_stem_grad_unpack(ws + n->gpack, grads + c.w_off, 64, st));
+    } else {
+        OSI_TRY(osi_conv_wgrad(&c.d, g, conv_in, grads + c.w_off, ws + n->wg_ws, n->wg_ws_bytes, st));
+    }
+    return OSI_OK;
+}
+
+int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, void* workspace, const float* dlogits,
+                          const float* dfeatures, int stage_lo, int stage_hi, osi_stream_t stream) {
+    OSI_REQUIRE(n && params && grads && workspace);
+    OSI_REQUIRE(stage_lo >= 0 && stage_lo < stage_hi && stage_hi <= n->n_stages);
+    if (!n->fwd_done || stage_lo != n->next_stage) return OSI_ERR_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    auto S = [&](int i) { return ws + n->scratch[i]; };
+
+    for (int stage = stage_lo; stage < stage_hi; ++stage) {
+        if (stage == 0) {
+            OSI_REQUIRE(dlogits);
+            n->free_list.clear();
+            for (int i = 5; i >= 0; --i) n->free_list.push_back(i);
+            const Tensor& fw = n->tensors[n->t_fc_w]; const Tensor& fb = n->tensors[n->t_fc_b]; const Tensor& lw = n->tensors[n->t_lg_w];
+            float* dfeat = ws + n->dfeat;
+            int acc = 0;
+            if (dfeatures) {
+                if (hipMemcpyAsync(dfeat, dfeatures, (size_t)n->B * n->F * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return OSI_ERR_LAUNCH;
+                acc = 1;
+            }
+            float* dlb = n->t_lg_b >= 0 ? grads + n->tensors[n->t_lg_b].off : nullptr;
+            OSI_TRY(osi_linear_bwd(dlogits, ws + n->feat, params + lw.off, dfeat, acc, grads + lw.off, dlb, n->B, n->F, n->O, st));
+            OSI_TRY(osi_linear_bwd(dfeat, ws + n->pooled, params + fw.off, ws + n->dpooled, 0, grads + fw.off, grads + fb.off, n->B,
+                                   2048, n->F, st));
+            int g = n->take();
+            OSI_TRY(osi_avgpool_bwd(ws + n->dpooled, S(g), n->B, n->Hf * n->Wf, 2048, st));
+            n->cur_grad = g;
+        }
+        for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
+            Block& k = n->blocks[bi];
+            if (k.stage != stage) continue;
+            int go = n->cur_grad;
+            const float* x = ws + k.x_in;
+            const float* out = ws + k.out;
+            Conv &c1 = n->convs[k.c1], &c2 = n->convs[k.c2], &c3 = n->convs[k.c3];
+            int dx = n->take();
+            if (dx < 0) return OSI_ERR_STATE;
+            if (k.ds >= 0) {
+                Conv& cd = n->convs[k.ds];
+                BN& bd = n->bns[cd.bn];
+                int t1 = n->take();
+                if (t1 < 0) return OSI_ERR_STATE;
+                // downsample branch: g = dOut*(out>0) -> BN -> conv
+                OSI_TRY(osi_bn_backward(S(go), out, ws + cd.y, ws + bd.mean, ws + bd.invstd, params + bd.g_off, S(t1), nullptr,
+                                        grads + bd.g_off, grads + bd.b_off, bd.M, bd.C, ws + n->bn_ws, n->bn_ws_bytes, st));
+                OSI_TRY(osi_conv_wgrad(&cd.d, S(t1), x, grads + cd.w_off, ws + n->wg_ws, n->wg_ws_bytes, st));
+                OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dx), 0, OSI_TILE_AUTO, st));
+                n->give(t1);
+                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, S(go), out, nullptr, ws + c2.a, st));
+            } else {
+                // identity skip: the masked gradient itself continues to the block input
+                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, S(go), out, S(dx), ws + c2.a, st));
+            }
+            int t2 = n->take();
+            if (t2 < 0) return OSI_ERR_STATE;
+            OSI_TRY(osi_conv_dgrad(&c3.d, S(go), params + c3.w_off, S(t2), 0, OSI_TILE_AUTO, st));
+            n->give(go);
+            OSI_TRY(bn_conv_wgrad(n, k.c2, params, grads, ws, S(t2), ws + c2.a, nullptr, ws + c1.a, st));
+            int t3 = n->take();
+            if (t3 < 0) return OSI_ERR_STATE;
+            OSI_TRY(osi_conv_dgrad(&c2.d, S(t2), params + c2.w_off, S(t3), 0, OSI_TILE_AUTO, st));
+            n->give(t2);
+            OSI_TRY(bn_conv_wgrad(n, k.c1, params, grads, ws, S(t3), ws + c1.a, nullptr, x, st));
+            OSI_TRY(osi_conv_dgrad(&c1.d, S(t3), params + c1.w_off, S(dx), 1, OSI_TILE_AUTO, st));
+            n->give(t3);
+            n->cur_grad = dx;
+        }
+        if (stage == n->n_stages - 1) {
+            // maxpool + stem
+            Conv& c0 = n->convs[0];
+            int go = n->cur_grad;
+            int t = n->take();
+            if (t < 0) return OSI_ERR_STATE;
+            OSI_TRY(osi_maxpool3x3s2_bwd(S(go), ws + n->pool_idx, S(t), n->B, n->Hs, n->Ws, 64, st));
+            n->give(go);
+            OSI_TRY(bn_conv_wgrad(n, 0, params, grads, ws, S(t), ws + c0.a, nullptr, ws + n->x4, st));
+            n->give(t);
+            n->cur_grad = -1;
+            n->fwd_done = false;
+        }
+        n->next_stage = stage + 1;
+    }
+    return OSI_OK;
+}
+
+}  // extern "C"

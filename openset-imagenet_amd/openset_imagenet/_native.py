@@ -1,0 +1,133 @@
+"""ctypes binding of libosi_hip.so (C ABI declared in include/osi.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback. Importing this module never needs a GPU
+(the .so only links the HIP runtime), but every compute entry point requires device pointers on an MI355X, and
+`lib()` raises if the shared object has not been built (`python __graft_entry__.py` / `make -C csrc`).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER, Structure
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+LIB_PATH = os.path.join(CSRC_DIR, "libosi_hip.so")
+
+OSI_OK = 0
+TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64 = 0, 1, 2, 3, 4
+LOSS_ENTROPIC, LOSS_SOFTMAX, LOSS_GARBAGE = 0, 1, 2
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "R", "S", "stride", "pad")]
+
+    @classmethod
+    def make(cls, B, H, W, Cin, Cout, k, stride, pad):
+        Ho = (H + 2 * pad - k) // stride + 1
+        Wo = (W + 2 * pad - k) // stride + 1
+        return cls(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad)
+
+
+P = c_void_p
+_PD = POINTER(ConvDesc)
+
+# name -> (restype, argtypes). Must list every symbol of include/osi.h (tests/test_abi.py checks the header against it).
+_SIGS = {
+    "osi_abi_version": (c_int, []),
+    "osi_build_arch": (c_char_p, []),
+    "osi_strerror": (c_char_p, [c_int]),
+    "osi_conv_fwd": (c_int, [_PD, P, P, P, c_int, P]),
+    "osi_conv_dgrad": (c_int, [_PD, P, P, P, c_int, c_int, P]),
+    "osi_conv_wgrad_workspace": (c_size_t, [_PD]),
+    "osi_conv_wgrad": (c_int, [_PD, P, P, P, P, c_size_t, P]),
+    "osi_stem_weight_pack": (c_int, [P, P, c_int, P]),
+    "osi_stem_grad_unpack": (c_int, [P, P, c_int, P]),
+    "osi_bn_workspace": (c_size_t, [c_int, c_int]),
+    "osi_bn_train_stats": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),
+    "osi_bn_eval_coeffs": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),
+    "osi_bn_apply": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    "osi_bn_backward_workspace": (c_size_t, [c_int, c_int]),
+    "osi_bn_backward": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
+    "osi_nchw3_to_nhwc4": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "osi_maxpool3x3s2_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "osi_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "osi_avgpool_fwd": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "osi_avgpool_bwd": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "osi_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "osi_linear_bwd": (c_int, [P, P, P, P, c_int, P, P, c_int, c_int, c_int, P]),
+    "osi_loss_fwd_bwd": (c_int, [c_int, P, P, c_int, c_int, c_float, c_longlong, P, P, c_int, c_float, c_float, P, P, P, P]),
+    "osi_softmax": (c_int, [P, P, c_int, c_int, P]),
+    "osi_adam_step": (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_longlong, c_float, P]),
+    "osi_sgd_step": (c_int, [P, P, P, c_size_t, c_float, c_float, c_int, c_float, P]),
+    "osi_fill_f32": (c_int, [P, c_size_t, c_float, P]),
+    "osi_scale_f32": (c_int, [P, c_size_t, c_float, P]),
+    "osi_i64_add": (c_int, [P, c_int, c_longlong, P]),
+    "osi_resnet50_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int]),
+    "osi_resnet50_destroy": (None, [c_void_p]),
+    "osi_resnet50_num_tensors": (c_int, [c_void_p]),
+    "osi_resnet50_tensor_info": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t)]),
+    "osi_resnet50_param_floats": (c_size_t, [c_void_p]),
+    "osi_resnet50_num_bn": (c_int, [c_void_p]),
+    "osi_resnet50_bn_info": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t)]),
+    "osi_resnet50_buffer_floats": (c_size_t, [c_void_p]),
+    "osi_resnet50_workspace_bytes": (c_size_t, [c_void_p]),
+    "osi_resnet50_num_stages": (c_int, [c_void_p]),
+    "osi_resnet50_stage_grad_range": (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    "osi_resnet50_forward": (c_int, [c_void_p, P, P, P, P, P, P, P, c_int, P]),
+    "osi_resnet50_backward": (c_int, [c_void_p, P, P, P, P, P, c_int, c_int, P]),
+}
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library; raises NativeLibraryMissing when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found: build the gfx950 HIP library first (python __graft_entry__.py, or make -C {CSRC_DIR}). "
+                "There is no CPU fallback for the training hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError here = ABI drift, loud on purpose
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def check(code, what=""):
+    if code != OSI_OK:
+        msg = lib().osi_strerror(code).decode()
+        raise RuntimeError(f"libosi_hip {what} failed: {msg} (code {code})")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    """The current HIP stream of the tensor's device as an integer handle."""
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_gpu_f32(*tensors):
+    import torch
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("openset_imagenet (MI355X build): tensors must live on the GPU — there is no CPU fallback "
+                               "(set_device_gpu(index) / model.to('cuda')).")
+        if t.dtype != torch.float32 and t.dtype != torch.int64:
+            raise RuntimeError(f"unsupported dtype {t.dtype}: the hot path is fp32 (labels int64)")

@@ -1,0 +1,154 @@
+"""Open-set training losses as single fused HIP launches, plus the host-side meters of the reference loop.
+
+Call contract of the reference (openset_imagenet/losses.py:7-29 and train.py:341-347): a loss object is called as
+`j = loss_fn(logits[B,C] float32, target[B] int64)` and returns a 0-dim tensor supporting `.item()` and `.backward()`.
+
+  EntropicOpensetLoss(num_of_classes, unk_weight=1)   reference losses.py:9-29
+  SoftmaxLoss(ignore_index=-1)                         = torch.nn.CrossEntropyLoss(ignore_index=-1),   train.py:343
+  GarbageLoss(class_weights)                           = torch.nn.CrossEntropyLoss(weight=class_weights), train.py:344-347
+  ObjectosphereLoss(num_of_classes, unk_weight, xi, alpha)  NOT in the reference snapshot (only metrics.predict_objectosphere,
+        metrics.py:45-62): entropic loss + alpha/B * sum_i r_i^2 on the deep features, r_i = max(xi - |f_i|, 0) for knowns and
+        |f_i| for unknowns (Dhamija et al. 2018). Called as loss_fn(logits, target, features). Parity: unpinned by the reference.
+
+Each call is ONE kernel (osi_loss_fwd_bwd): log-softmax, the loss value and dJ/dlogits in one pass, no [B,C] target
+matrix, no `torch.sum(unk_idx).item()` host sync (reference losses.py:26). AverageMeter / EarlyStopping are host-side
+bookkeeping with the reference's semantics (losses.py:32-94).
+"""
+import torch
+
+from . import _native as N
+
+
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, features, cfg):
+        mode, unk_w, ignore_index, class_w, xi, alpha = cfg
+        N.require_gpu_f32(logits, target, features, class_w)
+        if logits.dim() != 2 or target.dim() != 1 or target.shape[0] != logits.shape[0]:
+            raise ValueError("expected logits [B, C] and target [B]")
+        if target.dtype != torch.int64:
+            raise TypeError("target must be int64")
+        logits_c = logits.contiguous().float()
+        target_c = target.contiguous()
+        B, C = logits_c.shape
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
+        dlogits = torch.empty_like(logits_c) if need_grad else None
+        feats_c = dfeat = None
+        Fdim = 0
+        if features is not None:
+            feats_c = features.contiguous().float()
+            Fdim = feats_c.shape[1]
+            dfeat = torch.empty_like(feats_c)
+        N.check(N.lib().osi_loss_fwd_bwd(mode, N.ptr(logits_c), N.ptr(target_c), B, C, float(unk_w), int(ignore_index),
+                                         N.ptr(class_w), N.ptr(feats_c), Fdim, float(xi), float(alpha), N.ptr(loss),
+                                         N.ptr(dlogits), N.ptr(dfeat), N.stream_of(logits_c)), "osi_loss_fwd_bwd")
+        ctx.save_for_backward(dlogits if dlogits is not None else loss.new_empty(0),
+                              dfeat if dfeat is not None else loss.new_empty(0))
+        ctx.has_feat = features is not None
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dlogits, dfeat = ctx.saved_tensors
+        gl = dlogits * grad_out if dlogits.numel() else None
+        gf = dfeat * grad_out if ctx.has_feat and dfeat.numel() else None
+        return gl, None, gf, None
+
+
+class EntropicOpensetLoss:
+    """Entropic open-set loss (reference losses.py:7-29): one-hot targets for y >= 0, w/C for every negative label,
+    mean over all rows of the batch."""
+
+    def __init__(self, num_of_classes, unk_weight=1):
+        self.class_count = int(num_of_classes)
+        self.unk_weight = float(unk_weight)
+        self.unknowns_multiplier = self.unk_weight / self.class_count
+
+    def __call__(self, logits, target):
+        if logits.shape[1] != self.class_count:
+            raise ValueError(f"logits have {logits.shape[1]} classes, loss was built for {self.class_count}")
+        return _FusedLoss.apply(logits, target, None, (N.LOSS_ENTROPIC, self.unk_weight, -1, None, 0.0, 0.0))
+
+
+class SoftmaxLoss:
+    """torch.nn.CrossEntropyLoss(ignore_index=-1) of reference train.py:343."""
+
+    def __init__(self, ignore_index=-1):
+        self.ignore_index = int(ignore_index)
+
+    def __call__(self, logits, target):
+        return _FusedLoss.apply(logits, target, None, (N.LOSS_SOFTMAX, 1.0, self.ignore_index, None, 0.0, 0.0))
+
+
+class GarbageLoss:
+    """torch.nn.CrossEntropyLoss(weight=class_weights) of reference train.py:344-347 (background class = last index)."""
+
+    def __init__(self, class_weights):
+        self.weight = class_weights.detach().float().contiguous()
+
+    def __call__(self, logits, target):
+        if self.weight.device != logits.device:
+            self.weight = self.weight.to(logits.device)
+        if self.weight.numel() != logits.shape[1]:
+            raise ValueError("class_weights length must equal the number of logits")
+        return _FusedLoss.apply(logits, target, None, (N.LOSS_GARBAGE, 1.0, -100, self.weight, 0.0, 0.0))
+
+
+class ObjectosphereLoss:
+    """Entropic open-set loss + feature-magnitude term (build-defined, see module docstring)."""
+
+    def __init__(self, num_of_classes, unk_weight=1, xi=10.0, alpha=1e-4):
+        self.class_count = int(num_of_classes)
+        self.unk_weight, self.xi, self.alpha = float(unk_weight), float(xi), float(alpha)
+
+    def __call__(self, logits, target, features):
+        return _FusedLoss.apply(logits, target, features,
+                                (N.LOSS_ENTROPIC, self.unk_weight, -1, None, self.xi, self.alpha))
+
+
+def softmax(logits):
+    """Row softmax on the GPU (validation path, reference train.py:177)."""
+    N.require_gpu_f32(logits)
+    x = logits.contiguous().float()
+    out = torch.empty_like(x)
+    N.check(N.lib().osi_softmax(N.ptr(x), N.ptr(out), x.shape[0], x.shape[1], N.stream_of(x)), "osi_softmax")
+    return out
+
+
+class AverageMeter:
+    """Running sample-weighted mean (reference losses.py:32-60)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val, self.avg, self.sum, self.count = 0, 0, 0, 0
+
+    def update(self, val, count=1):
+        self.val = val
+        self.sum += val * count
+        self.count += count
+        self.avg = self.sum / self.count
+
+    def __repr__(self):
+        return f"{self.avg:3.3f}"
+
+
+class EarlyStopping:
+    """Patience counter on a validation metric (reference losses.py:65-94)."""
+
+    def __init__(self, patience=100, delta=0):
+        self.patience, self.delta = patience, delta
+        self.counter, self.best_score, self.early_stop = 0, None, False
+
+    def __call__(self, metrics, loss=True):
+        score = -metrics if loss is True else metrics
+        if self.best_score is None:
+            self.best_score = score
+        elif score < self.best_score + self.delta:
+            self.counter += 1
+            if self.counter >= self.patience:
+                self.early_stop = True
+        else:
+            self.best_score, self.counter = score, 0

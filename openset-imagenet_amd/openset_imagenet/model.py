@@ -1,0 +1,270 @@
+"""ResNet50 with the deep-feature and logits layers of the reference, executed by libosi_hip on an MI355X.
+
+Drop-in for `openset_imagenet.model.ResNet50` (reference openset_imagenet/model.py:5-39):
+same constructor `ResNet50(fc_layer_dim, out_features, logit_bias)`, `forward(image) -> (logits, features)`,
+`model.logits.in_features / .out_features` (read at reference train.py:210-211) and the same 321 `state_dict()`
+keys (`resnet_base.conv1.weight` ... `resnet_base.fc.bias`, `logits.weight`), so reference checkpoints load.
+
+What is different underneath (nothing of torchvision / ATen / MIOpen runs):
+  * all 162 parameter tensors are views into ONE flat fp32 arena (`_flat_params`), gradients into a second arena of the
+    same layout (`_flat_grads`), BN running statistics into a third; conv weights keep the logical OIHW shape but are
+    stored KRSC (= channels_last strides), which is what the implicit-GEMM kernels read directly;
+  * `forward` is one C call (`osi_resnet50_forward`) that enqueues the whole network on the current HIP stream;
+    `backward` is `osi_resnet50_backward`, run stage by stage so that a gradient all-reduce (dp.py) can start on the
+    finished part of the arena while earlier layers are still being differentiated.
+There is no CPU path: calling the module with a CPU tensor raises.
+"""
+import ctypes
+import math
+import weakref
+
+import torch
+from torch import nn
+
+from . import _native as N
+
+
+class _Node(nn.Module):
+    """Pure container mirroring one torchvision sub-module in the state_dict hierarchy (no forward of its own)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("sub-modules of the MI355X ResNet50 are parameter containers; call the model itself")
+
+
+class _Net:
+    """Owner of one executor handle (fixed batch / image size)."""
+
+    def __init__(self, B, H, W, F, O, logit_bias):
+        self.h = ctypes.c_void_p()
+        N.check(N.lib().osi_resnet50_create(ctypes.byref(self.h), B, H, W, F, O, int(bool(logit_bias))), "osi_resnet50_create")
+        self.ws_bytes = N.lib().osi_resnet50_workspace_bytes(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                N.lib().osi_resnet50_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class _BackboneFn(torch.autograd.Function):
+    """Autograd node standing for the whole network: parameter gradients are written straight into the gradient arena."""
+
+    @staticmethod
+    def forward(ctx, image, anchor, model):
+        ctx.model = model
+        ctx.set_materialize_grads(False)
+        return model._run_forward(image, True)
+
+    @staticmethod
+    def backward(ctx, dlogits, dfeatures):
+        ctx.model._run_backward(dlogits, dfeatures)
+        return None, None, None
+
+
+class ResNet50(nn.Module):
+    """Represents a ResNet50 model (reference model.py:5)."""
+
+    def __init__(self, fc_layer_dim=1000, out_features=1000, logit_bias=True):
+        super().__init__()
+        self._F, self._O, self._logit_bias = int(fc_layer_dim), int(out_features), bool(logit_bias)
+        lib = N.lib()
+        probe = _Net(1, 32, 32, self._F, self._O, self._logit_bias)  # layout does not depend on batch / image size
+        self._n_stages = lib.osi_resnet50_num_stages(probe.h)
+        nparam = lib.osi_resnet50_param_floats(probe.h)
+        nbuf = lib.osi_resnet50_buffer_floats(probe.h)
+        nbn = lib.osi_resnet50_num_bn(probe.h)
+        object.__setattr__(self, "_flat_params", torch.zeros(nparam))
+        object.__setattr__(self, "_flat_grads", torch.zeros(nparam))
+        object.__setattr__(self, "_flat_buffers", torch.zeros(nbuf))
+        object.__setattr__(self, "_nbt", torch.zeros(nbn, dtype=torch.int64))
+        object.__setattr__(self, "_anchor", torch.zeros(1, requires_grad=True))
+        self._stage_ranges = []
+        lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+        for s in range(self._n_stages):
+            N.check(lib.osi_resnet50_stage_grad_range(probe.h, s, ctypes.byref(lo), ctypes.byref(hi)))
+            self._stage_ranges.append((lo.value, hi.value))
+
+        # ---- build the module tree + parameter views -------------------------------------------------------
+        self._pinfo = []   # (name, offset, numel, shape)
+        self._binfo = []   # (node, buffer name, arena name, offset, numel)
+        name = ctypes.create_string_buffer(160)
+        nd, shp, off, ne = ctypes.c_int(), (ctypes.c_int * 4)(), ctypes.c_size_t(), ctypes.c_size_t()
+        bn_prefix = {}
+        C, rm, rv = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_size_t()
+        for j in range(nbn):
+            N.check(lib.osi_resnet50_bn_info(probe.h, j, name, 160, ctypes.byref(C), ctypes.byref(rm), ctypes.byref(rv)))
+            bn_prefix[name.value.decode()] = (j, C.value, rm.value, rv.value)
+        for i in range(lib.osi_resnet50_num_tensors(probe.h)):
+            N.check(lib.osi_resnet50_tensor_info(probe.h, i, name, 160, ctypes.byref(nd), shp, ctypes.byref(off), ctypes.byref(ne)))
+            full = name.value.decode()
+            shape = tuple(shp[k] for k in range(nd.value))
+            self._pinfo.append((full, off.value, ne.value, shape))
+            *path, leaf = full.split(".")
+            node = self._node(path)
+            node.register_parameter(leaf, nn.Parameter(self._view(self._flat_params, off.value, ne.value, shape)))
+            prefix = ".".join(path)
+            if leaf == "bias" and prefix in bn_prefix:
+                j, c, rmo, rvo = bn_prefix[prefix]
+                node.register_buffer("running_mean", self._flat_buffers[rmo:rmo + c])
+                node.register_buffer("running_var", self._flat_buffers[rvo:rvo + c])
+                node.register_buffer("num_batches_tracked", self._nbt[j])
+                self._binfo += [(node, "running_mean", "_flat_buffers", rmo, c), (node, "running_var", "_flat_buffers", rvo, c),
+                                (node, "num_batches_tracked", "_nbt", j, 0)]
+        self.logits.in_features, self.logits.out_features = self._F, self._O
+        self.resnet_base.fc.in_features, self.resnet_base.fc.out_features = 2048, self._F
+        self._plist = [dict(self.named_parameters())[n] for (n, _, _, _) in self._pinfo]
+        for p in self._plist:
+            p._osi_owner = weakref.ref(self)
+        self._nets = {}
+        self._ws = None
+        self._grad_sync = None   # set by dp.DistributedDataParallel
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------------------------------------------
+    def _node(self, path):
+        node = self
+        for comp in path:
+            if comp not in node._modules:
+                node.add_module(comp, _Node())
+            node = node._modules[comp]
+        return node
+
+    @staticmethod
+    def _view(arena, off, numel, shape):
+        flat = arena[off:off + numel]
+        if len(shape) == 4:  # logical OIHW over physical [O][H][W][I]
+            o, i, h, w = shape
+            return flat.view(o, h, w, i).permute(0, 3, 1, 2)
+        return flat.view(shape)
+
+    def reset_parameters(self):
+        """torchvision's initialisation: kaiming-normal(fan_out, relu) convs, BN weight 1 / bias 0, default nn.Linear."""
+        with torch.no_grad():
+            for (name, _, _, shape), p in zip(self._pinfo, self._plist):
+                if len(shape) == 4:
+                    nn.init.kaiming_normal_(p, mode="fan_out", nonlinearity="relu")
+                elif len(shape) == 2:
+                    nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                elif name.endswith("fc.bias") or name == "logits.bias":
+                    fan_in = 2048 if name.endswith("fc.bias") else self._F
+                    bound = 1 / math.sqrt(fan_in)
+                    nn.init.uniform_(p, -bound, bound)
+                elif name.endswith(".weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+            for node, bname, _, _, _ in self._binfo:
+                buf = node._buffers[bname]
+                buf.fill_(1.0) if bname == "running_var" else buf.zero_()
+
+    # ---- device / dtype movement keeps the arenas whole ---------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        new = {}
+        for arena in ("_flat_params", "_flat_grads", "_flat_buffers"):
+            t = fn(getattr(self, arena))
+            if t.dtype != torch.float32:
+                raise RuntimeError("the MI355X ResNet50 is fp32 only (parity dtype of the reference path)")
+            new[arena] = t.contiguous()
+        new["_nbt"] = fn(self._nbt).to(torch.int64)
+        anchor = fn(self._anchor.detach()).requires_grad_(True)
+        for k, v in new.items():
+            object.__setattr__(self, k, v)
+        object.__setattr__(self, "_anchor", anchor)
+        with torch.no_grad():
+            for (name, off, numel, shape), p in zip(self._pinfo, self._plist):
+                had_grad = p.grad is not None
+                p.data = self._view(self._flat_params, off, numel, shape)
+                if had_grad:
+                    p.grad = self._view(self._flat_grads, off, numel, shape)
+            for node, bname, arena, off, c in self._binfo:
+                src = getattr(self, arena)
+                node._buffers[bname] = src[off] if arena == "_nbt" else src[off:off + c]
+        self._ws = None
+        return self
+
+    # ---- arena access for the optimizer / DP layers -------------------------------------------------------
+    def flat_parameters(self):
+        return self._flat_params
+
+    def flat_gradients(self):
+        return self._flat_grads
+
+    def gradient_buckets(self):
+        """[(lo, hi)] float ranges of the gradient arena in the order backward finishes them (head first)."""
+        return list(self._stage_ranges)
+
+    def bind_gradients(self):
+        """Point every parameter's .grad at its slice of the gradient arena."""
+        for (name, off, numel, shape), p in zip(self._pinfo, self._plist):
+            if p.grad is None or p.grad.data_ptr() != self._flat_grads.data_ptr() + 4 * off:
+                p.grad = self._view(self._flat_grads, off, numel, shape)
+
+    # ---- execution -------------------------------------------------------------------------------------------
+    def _net(self, B, H, W):
+        key = (B, H, W)
+        if key not in self._nets:
+            self._nets[key] = _Net(B, H, W, self._F, self._O, self._logit_bias)
+        net = self._nets[key]
+        dev = self._flat_params.device
+        if self._ws is None or self._ws.numel() < net.ws_bytes or self._ws.device != dev:
+            self._ws = None
+            self._ws = torch.empty(net.ws_bytes, dtype=torch.uint8, device=dev)
+        return net
+
+    def _check_image(self, image):
+        if not isinstance(image, torch.Tensor) or image.dim() != 4 or image.shape[1] != 3:
+            raise ValueError("expected an image batch [B, 3, H, W]")
+        if not image.is_cuda or not self._flat_params.is_cuda:
+            raise RuntimeError("openset_imagenet (MI355X build) has no CPU path: move the model and the batch to the GPU "
+                               "(set_device_gpu(index); device(model); device(images)).")
+        if image.device != self._flat_params.device:
+            raise RuntimeError("image batch and model live on different devices")
+        if image.dtype != torch.float32:
+            raise TypeError("image batch must be float32 (reference: ToTensor(), train.py:259-263)")
+
+    def _run_forward(self, image, want_grad):
+        B, _, H, W = image.shape
+        image = image.contiguous()
+        net = self._net(B, H, W)
+        logits = torch.empty(B, self._O, device=image.device)
+        features = torch.empty(B, self._F, device=image.device)
+        N.check(N.lib().osi_resnet50_forward(net.h, N.ptr(self._flat_params), N.ptr(self._flat_buffers), N.ptr(self._nbt),
+                                             N.ptr(image), N.ptr(self._ws), N.ptr(logits), N.ptr(features),
+                                             1 if self.training else 0, N.stream_of(image)), "osi_resnet50_forward")
+        self._last = (net, image if want_grad else None)
+        return logits, features
+
+    def _run_backward(self, dlogits, dfeatures):
+        net, _ = self._last
+        lib = N.lib()
+        if dlogits is None:
+            dlogits = torch.zeros(net_shape(self, net)[0], self._O, device=self._flat_params.device)
+        dlogits = dlogits.contiguous().float()
+        dfeatures = None if dfeatures is None else dfeatures.contiguous().float()
+        st = N.stream_of(dlogits)
+        sync = self._grad_sync
+        for s in range(self._n_stages):
+            N.check(lib.osi_resnet50_backward(net.h, N.ptr(self._flat_params), N.ptr(self._flat_grads), N.ptr(self._ws),
+                                              N.ptr(dlogits), N.ptr(dfeatures), s, s + 1, st), "osi_resnet50_backward")
+            if sync is not None:
+                lo, hi = self._stage_ranges[s]
+                sync.bucket_ready(self._flat_grads, lo, hi)
+        if sync is not None:
+            sync.finish()
+        self.bind_gradients()
+
+    def forward(self, image):
+        """Forward pass: returns (logits, deep features) like the reference (model.py:28-39)."""
+        self._check_image(image)
+        if torch.is_grad_enabled() and self.training and self._plist[0].requires_grad:
+            return _BackboneFn.apply(image, self._anchor, self)
+        return self._run_forward(image, False)
+
+
+def net_shape(model, net):
+    for (B, H, W), n in model._nets.items():
+        if n is net:
+            return B, H, W
+    raise RuntimeError("unknown executor")

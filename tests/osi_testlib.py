@@ -1,0 +1,58 @@
+"""Helpers for the GPU parity tests: every call goes through the C ABI of libosi_hip.so (ctypes), torch is only the allocator."""
+import ctypes
+
+import torch
+
+from openset_imagenet import _native as N
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def nhwc(x):          # NCHW tensor -> contiguous NHWC copy
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):          # NHWC tensor -> NCHW view
+    return x.permute(0, 3, 1, 2)
+
+
+def krsc(w):          # OIHW -> [O][R][S][I]
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def oihw(w):
+    return w.permute(0, 3, 1, 2)
+
+
+def conv_fwd(x_nhwc, w_krsc, k, stride, pad, tile=0):
+    B, H, W, Cin = x_nhwc.shape
+    Cout = w_krsc.shape[0]
+    d = N.ConvDesc.make(B, H, W, Cin, Cout, k, stride, pad)
+    y = torch.empty(B, d.Ho, d.Wo, Cout, device=x_nhwc.device)
+    N.check(N.lib().osi_conv_fwd(ctypes.byref(d), N.ptr(x_nhwc), N.ptr(w_krsc), N.ptr(y), tile, S()), "conv_fwd")
+    return y
+
+
+def conv_dgrad(dy_nhwc, w_krsc, H, W, k, stride, pad, accumulate_into=None, tile=0):
+    B, Ho, Wo, Cout = dy_nhwc.shape
+    Cin = w_krsc.shape[3]
+    d = N.ConvDesc.make(B, H, W, Cin, Cout, k, stride, pad)
+    assert (d.Ho, d.Wo) == (Ho, Wo)
+    dx = accumulate_into if accumulate_into is not None else torch.full((B, H, W, Cin), float("nan"), device=dy_nhwc.device)
+    N.check(N.lib().osi_conv_dgrad(ctypes.byref(d), N.ptr(dy_nhwc), N.ptr(w_krsc), N.ptr(dx), int(accumulate_into is not None), tile, S()), "conv_dgrad")
+    return dx
+
+
+def conv_wgrad(dy_nhwc, x_nhwc, k, stride, pad):
+    B, H, W, Cin = x_nhwc.shape
+    Cout = dy_nhwc.shape[3]
+    d = N.ConvDesc.make(B, H, W, Cin, Cout, k, stride, pad)
+    stem = Cin == 4 and k == 7
+    ktot = 224 if stem else k * k * Cin
+    dw = torch.full((Cout, ktot), float("nan"), device=x_nhwc.device)
+    nbytes = N.lib().osi_conv_wgrad_workspace(ctypes.byref(d))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x_nhwc.device)
+    N.check(N.lib().osi_conv_wgrad(ctypes.byref(d), N.ptr(dy_nhwc), N.ptr(x_nhwc), N.ptr(dw), N.ptr(ws), nbytes, S()), "conv_wgrad")
+    return dw if stem else dw.view(Cout, k, k, Cin)

@@ -1,0 +1,334 @@
+"""GPU parity of every HIP kernel against torch-CPU arithmetic (fp32, with an fp64 arbiter), through the C ABI.
+
+Tolerances: the MFMA f32 path is an exact-f32 fma chain, so a conv differs from ATen's CPU conv only by summation order:
+|err| <= ~1e-6 * sum|a*b|. Tests bound the error relative to the fp64 result and require it to be no worse than a few times
+the error torch-CPU-fp32 itself makes against fp64.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(a, ref64):
+    return float((a.double().cpu() - ref64).abs().max())
+
+
+def _check_vs64(got, ref32, ref64, what, slack=4.0, floor=2e-6):
+    """got must be as close to the fp64 truth as torch-CPU fp32 is (times slack), relative to the tensor's scale."""
+    scale = float(ref64.abs().max()) + 1e-30
+    e_got, e_ref = _err(got, ref64) / scale, _err(ref32, ref64) / scale
+    assert e_got <= max(slack * e_ref, floor), f"{what}: rel err {e_got:.3e} vs torch-cpu-fp32 {e_ref:.3e}"
+
+
+# (Cin, Cout, k, stride, pad, H) — every (k, stride) family of SURVEY.md Appendix A on reduced shapes, + ragged M
+CONV_CASES = [
+    (64, 64, 1, 1, 0, 14), (64, 256, 1, 1, 0, 9), (256, 64, 1, 1, 0, 12), (256, 128, 1, 1, 0, 7),
+    (64, 64, 3, 1, 1, 14), (128, 128, 3, 2, 1, 14), (128, 128, 3, 2, 1, 9), (256, 512, 1, 2, 0, 14), (64, 128, 1, 2, 0, 7),
+    (512, 512, 3, 1, 1, 7), (2048, 512, 1, 1, 0, 7), (512, 2048, 1, 1, 0, 7), (128, 64, 3, 1, 1, 5),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,H", CONV_CASES)
+@pytest.mark.parametrize("B", [3])
+def test_conv_fwd_dgrad_wgrad(cuda, Cin, Cout, k, stride, pad, H, B):
+    import osi_testlib as T
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + k + H)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    y32 = F.conv2d(x, w, None, stride, pad)
+    y64 = F.conv2d(x.double(), w.double(), None, stride, pad)
+    dy = torch.randn(y32.shape, generator=g)
+    dx32 = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad)
+    dx64 = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), stride, pad)
+    dw32 = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride, pad)
+
+    xg, wg, dyg = T.nhwc(x).to(cuda), T.krsc(w).to(cuda), T.nhwc(dy).to(cuda)
+    tiles = [0, 4] + ([1, 3] if Cout % 128 == 0 else []) + [2]
+    for tile in tiles:
+        y = T.conv_fwd(xg, wg, k, stride, pad, tile)
+        _check_vs64(T.nchw(y), y32, y64, f"conv fwd tile {tile}")
+    tiles = [0, 4] + ([1, 3] if Cin % 128 == 0 else []) + [2]
+    for tile in tiles:
+        dx = T.conv_dgrad(dyg, wg, H, H, k, stride, pad, tile=tile)
+        assert not torch.isnan(dx).any(), "dgrad left input-gradient elements unwritten"
+        _check_vs64(T.nchw(dx), dx32, dx64, f"conv dgrad tile {tile}")
+    # accumulate mode: dx = base + dgrad
+    base = torch.randn(B, H, H, Cin, generator=g)
+    acc = T.conv_dgrad(dyg, wg, H, H, k, stride, pad, accumulate_into=base.to(cuda).clone())
+    _check_vs64(T.nchw(acc), dx32 + T.nchw(base), dx64 + T.nchw(base).double(), "conv dgrad accumulate")
+    dw = T.conv_wgrad(dyg, xg, k, stride, pad)
+    assert not torch.isnan(dw).any()
+    _check_vs64(T.oihw(dw), dw32, dw64, "conv wgrad")
+
+
+def test_conv_large_m_splitk(cuda):
+    """A shape whose weight gradient needs a deep split-K (K = B*Ho*Wo = 50176) and ragged last split."""
+    import osi_testlib as T
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, H = 4, 64, 64, 112
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24
+    dy = torch.randn(B, Cout, H, H, generator=g)
+    dw32 = torch.nn.grad.conv2d_weight(x, w.shape, dy, 1, 1)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, 1)
+    dw = T.conv_wgrad(T.nhwc(dy).to(cuda), T.nhwc(x).to(cuda), 3, 1, 1)
+    _check_vs64(T.oihw(dw), dw32, dw64, "wgrad split-K", slack=6.0)
+    dw2 = T.conv_wgrad(T.nhwc(dy).to(cuda), T.nhwc(x).to(cuda), 3, 1, 1)
+    assert torch.equal(dw, dw2), "split-K reduction must be bitwise reproducible"
+
+
+@pytest.mark.parametrize("B,H", [(2, 32), (3, 45)])
+def test_stem(cuda, B, H):
+    """7x7 stride-2 stem through the NCHW->NHWC4 staging + packed weights, fwd and wgrad."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    g = torch.Generator().manual_seed(H)
+    x = torch.rand(B, 3, H, H, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    y32, y64 = F.conv2d(x, w, None, 2, 3), F.conv2d(x.double(), w.double(), None, 2, 3)
+    xg = x.to(cuda)
+    x4 = torch.empty(B, H, H, 4, device=cuda)
+    N.check(N.lib().osi_nchw3_to_nhwc4(N.ptr(xg), N.ptr(x4), B, H, H, T.S()))
+    assert torch.equal(x4[..., :3].cpu(), x.permute(0, 2, 3, 1)) and float(x4[..., 3].abs().max()) == 0
+    wk = T.krsc(w).to(cuda)                       # [64][7][7][3] — the parameter's physical layout
+    wp = torch.empty(64, 224, device=cuda)
+    N.check(N.lib().osi_stem_weight_pack(N.ptr(wk), N.ptr(wp), 64, T.S()))
+    y = T.conv_fwd(x4, wp, 7, 2, 3)
+    _check_vs64(T.nchw(y), y32, y64, "stem fwd")
+    dy = torch.randn(y32.shape, generator=g)
+    dw32 = torch.nn.grad.conv2d_weight(x, w.shape, dy, 2, 3)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 2, 3)
+    gp = T.conv_wgrad(T.nhwc(dy).to(cuda), x4, 7, 2, 3)
+    gk = torch.empty(64, 7, 7, 3, device=cuda)
+    N.check(N.lib().osi_stem_grad_unpack(N.ptr(gp), N.ptr(gk), 64, T.S()))
+    _check_vs64(T.oihw(gk), dw32, dw64, "stem wgrad")
+
+
+@pytest.mark.parametrize("B,C,H", [(4, 64, 14), (3, 256, 7), (2, 2048, 3), (5, 12, 6), (2, 64, 56)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_batchnorm(cuda, B, C, H, relu, res):
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(C + H)
+    y = torch.randn(B, C, H, H, generator=g) * 2 + torch.randn(1, C, 1, 1, generator=g) * 5   # non-zero means
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm0, rv0 = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    resid = torch.randn(B, C, H, H, generator=g) if res else None
+    dout = torch.randn(B, C, H, H, generator=g)
+
+    def ref(dt):
+        yy = y.to(dt).requires_grad_(True)
+        ga, be = gamma.to(dt).requires_grad_(True), beta.to(dt).requires_grad_(True)
+        rm, rv = rm0.to(dt).clone(), rv0.to(dt).clone()
+        o = F.batch_norm(yy, rm, rv, ga, be, True, 0.1, 1e-5)
+        if res:
+            o = o + resid.to(dt)
+        if relu:
+            o = F.relu(o)
+        o.backward(dout.to(dt))
+        return o.detach(), yy.grad, ga.grad, be.grad, rm, rv
+    r32, r64 = ref(torch.float32), ref(torch.float64)
+
+    M = B * H * H
+    yg = T.nhwc(y).to(cuda)
+    dev = lambda t: t.to(cuda).contiguous()
+    ga, be, rm, rv = dev(gamma), dev(beta), dev(rm0), dev(rv0)
+    mean, invstd, scale, shift = (torch.empty(C, device=cuda) for _ in range(4))
+    wsb = max(L.osi_bn_workspace(M, C), L.osi_bn_backward_workspace(M, C))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    N.check(L.osi_bn_train_stats(N.ptr(yg), M, C, N.ptr(ga), N.ptr(be), 1e-5, 0.1, N.ptr(rm), N.ptr(rv), N.ptr(mean), N.ptr(invstd),
+                                 N.ptr(scale), N.ptr(shift), N.ptr(ws), wsb, T.S()))
+    out = torch.empty_like(yg)
+    rg = T.nhwc(resid).to(cuda) if res else None
+    N.check(L.osi_bn_apply(N.ptr(yg), N.ptr(rg), N.ptr(scale), N.ptr(shift), N.ptr(out), M, C, int(relu), T.S()))
+    _check_vs64(T.nchw(out), r32[0], r64[0], "bn out")
+    _check_vs64(rm, r32[4], r64[4], "running_mean")
+    _check_vs64(rv, r32[5], r64[5], "running_var")
+    dg, db = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    dy = torch.empty_like(yg)
+    gm = torch.empty_like(yg)
+    dog = T.nhwc(dout).to(cuda)
+    N.check(L.osi_bn_backward(N.ptr(dog), N.ptr(out) if relu else None, N.ptr(yg), N.ptr(mean), N.ptr(invstd), N.ptr(ga), N.ptr(dy),
+                              N.ptr(gm), N.ptr(dg), N.ptr(db), M, C, N.ptr(ws), wsb, T.S()))
+    _check_vs64(T.nchw(dy), r32[1], r64[1], "bn dy", slack=8.0, floor=5e-6)
+    _check_vs64(dg, r32[2], r64[2], "bn dgamma", slack=8.0, floor=5e-6)
+    _check_vs64(db, r32[3], r64[3], "bn dbeta", slack=8.0, floor=5e-6)
+    mask = (r64[0] > 0) if relu else torch.ones_like(r64[0], dtype=torch.bool)
+    assert torch.allclose(T.nchw(gm).cpu(), dout * mask, atol=0), "masked upstream gradient"
+    # in-place form (dy aliases dout) gives the same bits
+    N.check(L.osi_bn_backward(N.ptr(dog), N.ptr(out) if relu else None, N.ptr(yg), N.ptr(mean), N.ptr(invstd), N.ptr(ga), N.ptr(dog),
+                              None, N.ptr(dg), N.ptr(db), M, C, N.ptr(ws), wsb, T.S()))
+    assert torch.equal(dog, dy)
+
+
+def test_bn_eval_coeffs(cuda):
+    from openset_imagenet import _native as N
+    import osi_testlib as T
+    C = 64
+    g = torch.Generator().manual_seed(0)
+    rm, rv, ga, be = torch.randn(C, generator=g), torch.rand(C, generator=g) + .1, torch.randn(C, generator=g), torch.randn(C, generator=g)
+    x = torch.randn(2, C, 5, 5, generator=g)
+    ref = F.batch_norm(x, rm, rv, ga, be, False, 0.1, 1e-5)
+    sc, sh = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    N.check(N.lib().osi_bn_eval_coeffs(N.ptr(rm.to(cuda)), N.ptr(rv.to(cuda)), N.ptr(ga.to(cuda)), N.ptr(be.to(cuda)), 1e-5, C, N.ptr(sc), N.ptr(sh), T.S()))
+    xg = T.nhwc(x).to(cuda)
+    out = torch.empty_like(xg)
+    N.check(N.lib().osi_bn_apply(N.ptr(xg), None, N.ptr(sc), N.ptr(sh), N.ptr(out), 50, C, 0, T.S()))
+    assert torch.allclose(T.nchw(out).cpu(), ref, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,H", [(2, 64, 16), (3, 64, 15), (1, 8, 7)])
+def test_maxpool(cuda, B, C, H):
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    g = torch.Generator().manual_seed(H)
+    x = F.relu(torch.randn(B, C, H, H, generator=g)).requires_grad_(True)   # post-ReLU input: many exact ties at 0
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    Ho = y.shape[2]
+    xg = T.nhwc(x.detach()).to(cuda)
+    yg = torch.empty(B, Ho, Ho, C, device=cuda)
+    idx = torch.empty(B * Ho * Ho * C, dtype=torch.uint8, device=cuda)
+    N.check(N.lib().osi_maxpool3x3s2_fwd(N.ptr(xg), N.ptr(yg), N.ptr(idx), B, H, H, C, T.S()))
+    assert torch.equal(T.nchw(yg).cpu(), y.detach())
+    dx = torch.empty_like(xg)
+    N.check(N.lib().osi_maxpool3x3s2_bwd(N.ptr(T.nhwc(dy).to(cuda)), N.ptr(idx), N.ptr(dx), B, H, H, C, T.S()))
+    assert torch.allclose(T.nchw(dx).cpu(), x.grad, atol=1e-6), "maxpool backward (first-max tie rule)"
+
+
+def test_avgpool(cuda):
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 2048, 7, 7, generator=g).requires_grad_(True)
+    y = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+    dy = torch.randn(3, 2048, generator=g)
+    y.backward(dy)
+    xg = T.nhwc(x.detach()).to(cuda)
+    yg = torch.empty(3, 2048, device=cuda)
+    N.check(N.lib().osi_avgpool_fwd(N.ptr(xg), N.ptr(yg), 3, 49, 2048, T.S()))
+    assert torch.allclose(yg.cpu(), y.detach(), atol=1e-6)
+    dx = torch.empty_like(xg)
+    N.check(N.lib().osi_avgpool_bwd(N.ptr(dy.to(cuda)), N.ptr(dx), 3, 49, 2048, T.S()))
+    assert torch.allclose(T.nchw(dx).cpu(), x.grad, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,K,O,bias", [(5, 2048, 116, True), (7, 30, 30, False), (3, 151, 151, False), (128, 2048, 152, True)])
+def test_linear(cuda, B, K, O, bias):
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    g = torch.Generator().manual_seed(K + O)
+    x, w, b = torch.randn(B, K, generator=g), torch.randn(O, K, generator=g) / K ** .5, torch.randn(O, generator=g)
+    dy = torch.randn(B, O, generator=g)
+
+    def ref(dt):
+        xx, ww, bb = x.to(dt).requires_grad_(True), w.to(dt).requires_grad_(True), b.to(dt).requires_grad_(True)
+        y = F.linear(xx, ww, bb if bias else None)
+        y.backward(dy.to(dt))
+        return y.detach(), xx.grad, ww.grad, bb.grad if bias else None
+    r32, r64 = ref(torch.float32), ref(torch.float64)
+    xg, wg, bg, dyg = x.to(cuda), w.to(cuda), b.to(cuda), dy.to(cuda)
+    y = torch.empty(B, O, device=cuda)
+    N.check(N.lib().osi_linear_fwd(N.ptr(xg), N.ptr(wg), N.ptr(bg) if bias else None, N.ptr(y), B, K, O, T.S()))
+    _check_vs64(y, r32[0], r64[0], "linear fwd")
+    dx, dw, db = torch.empty_like(xg), torch.empty_like(wg), torch.empty_like(bg)
+    N.check(N.lib().osi_linear_bwd(N.ptr(dyg), N.ptr(xg), N.ptr(wg), N.ptr(dx), 0, N.ptr(dw), N.ptr(db) if bias else None, B, K, O, T.S()))
+    _check_vs64(dx, r32[1], r64[1], "linear dx")
+    _check_vs64(dw, r32[2], r64[2], "linear dw")
+    if bias:
+        _check_vs64(db, r32[3], r64[3], "linear db")
+
+
+def _run_loss(cuda, mode, z, y, w=1.0, cw=None, feats=None, xi=0.0, alpha=0.0, want_grad=True):
+    from openset_imagenet import _native as N
+    import osi_testlib as T
+    zg, yg = z.to(cuda).contiguous(), y.to(cuda)
+    loss = torch.empty((), device=cuda)
+    dz = torch.full_like(zg, float("nan")) if want_grad else None
+    fg = feats.to(cuda).contiguous() if feats is not None else None
+    df = torch.full_like(fg, float("nan")) if fg is not None else None
+    cwg = cw.to(cuda).contiguous() if cw is not None else None
+    N.check(N.lib().osi_loss_fwd_bwd(mode, N.ptr(zg), N.ptr(yg), z.shape[0], z.shape[1], float(w), -1, N.ptr(cwg), N.ptr(fg),
+                                     feats.shape[1] if feats is not None else 0, float(xi), float(alpha), N.ptr(loss), N.ptr(dz), N.ptr(df), T.S()))
+    return loss.cpu(), None if dz is None else dz.cpu(), None if df is None else df.cpu()
+
+
+def test_losses_vs_reference_golden(cuda, golden_dir):
+    """HIP loss kernels against vectors produced by the reference's own losses.py / CrossEntropyLoss calls."""
+    from openset_imagenet import _native as N
+    G = np.load(f"{golden_dir}/losses_reference.npz")
+    for fam, mode in (("eos", N.LOSS_ENTROPIC), ("sm", N.LOSS_SOFTMAX), ("gb", N.LOSS_GARBAGE)):
+        for name in G[f"{fam}.names"]:
+            p = f"{fam}.{name}."
+            z, y = torch.from_numpy(G[p + "logits"]), torch.from_numpy(G[p + "target"])
+            w = float(G[p + "w"]) if fam == "eos" else 1.0
+            cw = torch.from_numpy(G[p + "class_weights"]) if fam == "gb" else None
+            loss, dz, _ = _run_loss(cuda, mode, z, y, w, cw)
+            ref_loss, ref_dz = float(G[p + "loss"]), torch.from_numpy(G[p + "dlogits"])
+            if np.isnan(ref_loss):
+                assert torch.isnan(loss), f"{p}: all-ignored batch must give NaN like torch"
+                continue
+            assert abs(float(loss) - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss)), f"{p} loss {float(loss)} vs {ref_loss}"
+            assert float((dz - ref_dz).abs().max()) <= 2e-7 + 1e-6 * float(ref_dz.abs().max()), f"{p} dlogits"
+            loss2, _, _ = _run_loss(cuda, mode, z, y, w, cw, want_grad=False)
+            assert torch.equal(loss, loss2), "loss-only launch must give the same bits"
+
+
+def test_objectosphere_vs_oracle(cuda):
+    from oracle import losses_oracle as LO
+    from openset_imagenet import _native as N
+    g = torch.Generator().manual_seed(9)
+    B, C = 16, 30
+    z = torch.randn(B, C, generator=g) * 2
+    y = torch.randint(-1, C, (B,), generator=g)
+    f = torch.randn(B, C, generator=g) * 3
+    f[0] = 0  # |f| = 0: gradient defined as 0
+    for xi, alpha, w in ((10.0, 1e-2, 1.0), (3.0, 0.5, 0.5)):
+        z64, f64 = z.double().requires_grad_(True), f.double().requires_grad_(True)
+        J = LO.objectosphere_loss(z64, y, f64, w, xi, alpha)
+        J.backward()
+        loss, dz, df = _run_loss(cuda, N.LOSS_ENTROPIC, z, y, w, None, f, xi, alpha)
+        assert abs(float(loss) - float(J)) <= 2e-6 * max(1, abs(float(J)))
+        assert float((dz.double() - z64.grad).abs().max()) < 1e-6
+        assert float((df.double() - torch.nan_to_num(f64.grad)).abs().max()) < 1e-6 * max(1.0, float(f64.grad[1:].abs().max()))
+
+
+def test_softmax_kernel(cuda):
+    from openset_imagenet import _native as N
+    import osi_testlib as T
+    z = torch.randn(37, 151) * 4
+    out = torch.empty(37, 151, device=cuda)
+    N.check(N.lib().osi_softmax(N.ptr(z.to(cuda)), N.ptr(out), 37, 151, T.S()))
+    assert torch.allclose(out.cpu(), torch.softmax(z, 1), atol=1e-7, rtol=1e-5)
+
+
+@pytest.mark.parametrize("n", [4, 1000, 23759172])
+def test_adam_sgd_vs_torch(cuda, n):
+    from openset_imagenet import _native as N
+    import osi_testlib as T
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * (0.1 + i) for i in range(3)]
+    for kind in ("adam", "sgd"):
+        pt = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([pt], lr=1e-3) if kind == "adam" else torch.optim.SGD([pt], lr=1e-2, momentum=0.9)
+        pg = p0.to(cuda).clone()
+        s1, s2 = torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+        for i, gr in enumerate(grads):
+            pt.grad = gr.clone()
+            opt.step()
+            gg = gr.to(cuda)
+            if kind == "adam":
+                N.check(N.lib().osi_adam_step(N.ptr(pg), N.ptr(gg), N.ptr(s1), N.ptr(s2), n, 1e-3, 0.9, 0.999, 1e-8, i + 1, 1.0, T.S()))
+            else:
+                N.check(N.lib().osi_sgd_step(N.ptr(pg), N.ptr(gg), N.ptr(s1), n, 1e-2, 0.9, int(i == 0), 1.0, T.S()))
+        d = float((pg.cpu() - pt.detach()).abs().max())
+        assert d <= 1e-6, f"{kind}: max param diff {d}"
