@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the open-set ImageNet training step (ResNet-50 + entropic open-set loss) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]                       (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1, one rank per GPU)
+
+One step = the reference's inner-loop body (openset_imagenet/train.py:125-139): zero_grad, forward, loss, backward
+(+ bucketed RCCL gradient all-reduce when N > 1), optimizer step — on a synthetic batch that is already resident in HBM.
+Workload (all N, weak scaling): Protocol 2 shapes — C = 30 known classes, entropic open-set loss, batch 128 per GPU,
+3x224x224 fp32 images in [0,1), labels -1 with probability 0.5, Adam lr 1e-3, fp32 arithmetic throughout.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement for the fields).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "openset-imagenet_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work of the conv stack per image: fwd 8.1743, dgrad 7.9383 (no stem dgrad), wgrad 8.1743
+CONV_GFLOP_FWD, CONV_GFLOP_DGRAD, CONV_GFLOP_WGRAD = 8.1743, 7.9383, 8.1743
+CONV_GFLOP_PER_IMAGE = 24.287
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+WORKLOADS = {
+    "p2": dict(name="Protocol 2, ResNet-50, entropic open-set loss, batch 128/GPU", C=30, B=128, loss="entropic", p_neg=0.5),
+    "p1": dict(name="Protocol 1, ResNet-50, entropic open-set loss, batch 128/GPU", C=116, B=128, loss="entropic", p_neg=0.37),
+    "p3": dict(name="Protocol 3, ResNet-50, background-class softmax, batch 256/GPU", C=152, B=256, loss="garbage", p_neg=0.39),
+}
+
+
+def synthetic_batch(B, C, p_neg, loss, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    labels = torch.randint(0, C if loss != "garbage" else C - 1, (B,), generator=g)
+    neg = torch.rand(B, generator=g) < p_neg
+    labels[neg] = -1 if loss != "garbage" else C - 1
+    gd = torch.Generator(device=device).manual_seed(seed)
+    images = torch.rand(B, 3, 224, 224, device=device, generator=gd)
+    return images, labels.to(device)
+
+
+def cpu_baseline(C, p_neg, steps=2, B=32):
+    """The CPU oracle (torch-CPU restatement of the reference path) timed on this host's cores: fwd + loss + bwd + Adam."""
+    from oracle import resnet50_oracle as R, losses_oracle as L
+    torch.manual_seed(42)
+    sd = R.init_state(C, C, False)
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, C, (B,), generator=g)
+    y[torch.rand(B, generator=g) < p_neg] = -1
+    state, times = {}, []
+    fn = lambda lg, t, f: L.entropic_openset_loss(lg, t, 1.0)
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        _, _, _, grads = R.forward_backward(sd, x, y, fn)
+        R.adam_step(sd, grads, state, lr=1e-3)
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": round(B / best, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed steps (after 1 warm-up) of batch {B}, same shapes/loss as the GPU workload, best step {best:.2f} s; "
+                      f"oracle/resnet50_oracle.py (torch-CPU fp32 restatement; the reference package itself is not importable offline)",
+            "host_cpu_count": os.cpu_count()}
+
+
+def parity_probe(model, C, device):
+    """Same-run logits parity on one shared batch with shared (freshly initialised) weights: HIP path vs the CPU oracle in fp32
+    and in fp64 (the arbiter: torch-CPU fp32 is itself a few 1e-5 away from fp64 on this network)."""
+    from oracle import resnet50_oracle as R
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(8, 3, 224, 224, generator=g)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.train()
+    with torch.no_grad():
+        lg, _ = model(x.to(device))
+    lg = lg.cpu()
+    ref32, _ = R.forward({k: v.clone() for k, v in sd.items()}, x, True)
+    ref64, _ = R.forward({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}, x.double(), True)
+    model.load_state_dict({k: v.to(device) for k, v in sd.items()})  # undo the probe's running-stat update
+    return {"max_abs_logit_err_vs_cpu_oracle_fp32": float((lg - ref32).abs().max()),
+            "max_abs_logit_err_vs_cpu_oracle_fp64": float((lg.double() - ref64).abs().max()),
+            "cpu_fp32_vs_fp64": float((ref32.double() - ref64).abs().max()), "tolerance": 1e-4,
+            "probe": "train-mode forward, batch 8 at 224x224, shared weights at initialisation"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="p2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the headline config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumentation of the executor")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    from openset_imagenet import ResNet50, EntropicOpensetLoss, GarbageLoss, optim, tools, _native as N
+    from openset_imagenet.dp import DistributedDataParallel
+    N.lib()  # fail loudly if the HIP library is missing
+    dev = tools.set_device_gpu(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["B"] = args.batch
+    B, C = wl["B"], wl["C"]
+    torch.manual_seed(42)
+    model = tools.device(ResNet50(C, C, False))
+    net = DistributedDataParallel(model) if world > 1 else model
+    opt = optim.Adam(model.parameters(), lr=1e-3)
+    images, labels = synthetic_batch(B, C, wl["p_neg"], wl["loss"], dev, 42 + rank)
+    if wl["loss"] == "garbage":
+        from oracle import losses_oracle as LO  # class weights of the synthetic label histogram (host-side data prep)
+        loss_fn = GarbageLoss(LO.class_weights(torch.where(labels.cpu() == C - 1, -1, labels.cpu())))
+    else:
+        loss_fn = EntropicOpensetLoss(C, 1.0)
+
+    def step():
+        model.train()
+        opt.zero_grad()
+        logits, _ = net(images)
+        j = loss_fn(logits, labels)
+        j.backward()
+        opt.step()
+        return j
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    parity = parity_probe(model, C, dev) if (world == 1 and not args.no_cpu_baseline) else None
+    for _ in range(args.warmup):
+        step()
+    handle = model._net(B, 224, 224).h
+    profile = not args.no_profile
+    if profile:
+        N.check(N.lib().osi_resnet50_profile(handle, 1))
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    prof = None
+    if profile:
+        ms = (ctypes.c_double * 7)()
+        cnt = (ctypes.c_int * 7)()
+        N.check(N.lib().osi_resnet50_profile_read(handle, ms, cnt))
+        N.check(N.lib().osi_resnet50_profile(handle, 0))
+        names = ["start", "conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "other"]
+        prof = {n: {"ms_per_step": ms[i] / args.steps, "launch_groups_per_step": cnt[i] / args.steps} for i, n in enumerate(names) if i}
+    loss_value = float(last.detach())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        ips = world * B * args.steps / elapsed
+        out = {
+            "metric": "images/sec (whole node) ResNet-50 + entropic-open-set, Protocol 2, 1/2/4/8 GPUs",
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (device-resident U[0,1) images, random-init weights seed 42)",
+            "config": {"workload": wl["name"], "classes": C, "batch_per_gpu": B, "global_batch": B * world, "image": "3x224x224",
+                       "loss": wl["loss"], "optimizer": "adam lr=1e-3", "parallelism": f"dp{world}"},
+            "final_loss": round(loss_value, 5),
+            "step_mfma_frac": round(B * args.steps / elapsed * CONV_GFLOP_PER_IMAGE * 1e9 / (MFMA_F32_PEAK_TFLOPS * 1e12), 4),
+        }
+        if prof:
+            conv_ms = sum(prof[k]["ms_per_step"] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
+            achieved = B * CONV_GFLOP_PER_IMAGE * 1e9 / (conv_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": "implicit-GEMM conv (k_conv_fwd + k_conv_dgrad + k_conv_wgrad incl. split-K reduce), fp32 MFMA 32x32x2",
+                "how": f"24.287 GFLOP/img x {B} img per step / summed HIP-event duration of the conv launches per step ({conv_ms:.2f} ms), "
+                       "events recorded on the launch stream inside the timed region",
+                "per_class": {k: {"ms_per_step": round(v["ms_per_step"], 3),
+                                  "tflops": round(B * g / v["ms_per_step"], 2) if g else None}
+                              for (k, v), g in zip(prof.items(), (CONV_GFLOP_FWD, CONV_GFLOP_DGRAD, CONV_GFLOP_WGRAD, 0, 0, 0))},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(C, wl["p_neg"])
+            out["parity"] = parity
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,8 +101,8 @@ int osi_loss_fwd_bwd(int mode, const float* logits, const long long* target, int
 int osi_softmax(const float* logits, float* out, int B, int C, osi_stream_t stream); /* train.py:177 */
 
 /* ---- optimizer + arena utilities (train.py:356-359 construction, train.py:127,139 zero_grad/step) --- */
-int osi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
-                  float beta2, float eps, long long step, float grad_scale, osi_stream_t stream);
+int osi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                  double beta2, double eps, long long step, float grad_scale, osi_stream_t stream);
 int osi_sgd_step(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum, int first_step,
                  float grad_scale, osi_stream_t stream);
 int osi_fill_f32(float* p, size_t n, float value, osi_stream_t stream);
@@ -141,6 +141,13 @@ int osi_resnet50_forward(osi_resnet50_t net, const float* params, float* buffers
 /* runs backward stages [stage_lo, stage_hi) given dJ/dlogits and (optionally, may be NULL) dJ/dfeatures */
 int osi_resnet50_backward(osi_resnet50_t net, const float* params, float* grads, void* workspace, const float* dlogits,
                           const float* dfeatures, int stage_lo, int stage_hi, osi_stream_t stream);
+
+/* Optional HIP-event instrumentation of the executor (bench.py's roofline leg): one event after every op on the launch
+ * stream, attributed to a kernel class. profile_read synchronises on the last event — call it outside timed regions. */
+enum { OSI_PROF_START = 0, OSI_PROF_CONV_FWD = 1, OSI_PROF_CONV_DGRAD = 2, OSI_PROF_CONV_WGRAD = 3, OSI_PROF_BN_FWD = 4,
+       OSI_PROF_BN_BWD = 5, OSI_PROF_OTHER = 6, OSI_PROF_NCLASS = 7 };
+int osi_resnet50_profile(osi_resnet50_t net, int enable);
+int osi_resnet50_profile_read(osi_resnet50_t net, double* ms_per_class, int* ops_per_class);
 
 #ifdef __cplusplus
 }

@@ -9,14 +9,14 @@
 namespace {
 
 __global__ __launch_bounds__(256) void k_adam(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v,
-                                             size_t n4, float step_size, float b1, float b2, float eps, float sqrt_bc2,
-                                             float gscale) {
+                                             size_t n4, float step_size, float b2, float omb1, float omb2, float eps,
+                                             float sqrt_bc2, float gscale) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t step = (size_t)gridDim.x * 256;
     for (; i < n4; i += step) {
         f32x4 gg = g[i] * gscale, mm = m[i], vv = v[i], pp = p[i];
-        mm = mm + (gg - mm) * (1.f - b1);       // torch: exp_avg.lerp_(grad, 1-beta1)
-        vv = vv * b2 + gg * gg * (1.f - b2);    // torch: exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        mm = mm + (gg - mm) * omb1;              // torch: exp_avg.lerp_(grad, 1-beta1)
+        vv = vv * b2 + gg * gg * omb2;         // torch: exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
         f32x4 den;
         den.x = sqrtf(vv.x) / sqrt_bc2 + eps; den.y = sqrtf(vv.y) / sqrt_bc2 + eps;
         den.z = sqrtf(vv.z) / sqrt_bc2 + eps; den.w = sqrtf(vv.w) / sqrt_bc2 + eps;
@@ -61,13 +61,14 @@ static int sgrid(size_t n4) {
 
 extern "C" {
 
-int osi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
-                  float beta2, float eps, long long step, float grad_scale, osi_stream_t stream) {
+int osi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                  double beta2, double eps, long long step, float grad_scale, osi_stream_t stream) {
     OSI_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && n % 4 == 0 && step >= 1);
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(k_adam, dim3(sgrid(n / 4)), dim3(256), 0, (hipStream_t)stream, (f32x4*)param, (const f32x4*)grad,
-                       (f32x4*)exp_avg, (f32x4*)exp_avg_sq, n / 4, (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
+                       (f32x4*)exp_avg, (f32x4*)exp_avg_sq, n / 4, (float)(lr / bc1), (float)beta2, (float)(1.0 - beta1),
+                       (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2), grad_scale);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }

@@ -76,6 +76,17 @@ struct osi_resnet50 {
     int next_stage = 0;
     int cur_grad = -1;               // scratch index holding the upstream gradient between stages
     std::vector<int> free_list;
+    // optional HIP-event instrumentation: one event after every op, tagged with the op's class
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_cls;
+    int prof_n = 0;
+    void mark(int cls, hipStream_t st) {
+        if (!prof_on) return;
+        if (prof_n == (int)prof_ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; prof_ev.push_back(e); prof_cls.push_back(0); }
+        prof_cls[prof_n] = cls;
+        (void)hipEventRecord(prof_ev[prof_n++], st);
+    }
 
     size_t add_tensor(const std::string& name, int ndim, const int* shape) {
         Tensor t; t.name = name; t.ndim = ndim; t.numel = 1;
@@ -228,11 +239,35 @@ int osi_resnet50_stage_grad_range(osi_resnet50_t net, int s, size_t* lo, size_t*
     return OSI_OK;
 }
 
+int osi_resnet50_profile(osi_resnet50_t n, int enable) {
+    OSI_REQUIRE(n);
+    n->prof_on = enable != 0;
+    n->prof_n = 0;
+    return OSI_OK;
+}
+// Host-synchronising read-out (not a launch function): per-class elapsed milliseconds and op counts since enable/last read.
+int osi_resnet50_profile_read(osi_resnet50_t n, double* ms, int* count) {
+    OSI_REQUIRE(n && ms && count);
+    for (int k = 0; k < OSI_PROF_NCLASS; ++k) { ms[k] = 0; count[k] = 0; }
+    if (n->prof_n == 0) return OSI_OK;
+    if (hipEventSynchronize(n->prof_ev[n->prof_n - 1]) != hipSuccess) return OSI_ERR_LAUNCH;
+    for (int i = 1; i < n->prof_n; ++i) {
+        int c = n->prof_cls[i];
+        if (c == OSI_PROF_START) continue;  // gap between two executor calls (loss kernel, host work): not attributed
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, n->prof_ev[i - 1], n->prof_ev[i]) != hipSuccess) return OSI_ERR_LAUNCH;
+        ms[c] += t; count[c] += 1;
+    }
+    n->prof_n = 0;
+    return OSI_OK;
+}
+
 static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buffers, float* ws, const float* x, const float* w,
                        int training, hipStream_t st) {
     Conv& c = n->convs[ci];
     BN& b = n->bns[c.bn];
     OSI_TRY(osi_conv_fwd(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, st));
+    n->mark(OSI_PROF_CONV_FWD, st);
     if (training)
         OSI_TRY(osi_bn_train_stats(ws + c.y, b.M, b.C, params + b.g_off, params + b.b_off, 1e-5f, 0.1f, buffers + b.rm_off,
                                    buffers + b.rv_off, ws + b.mean, ws + b.invstd, ws + b.scale, ws + b.shift, ws + n->bn_ws,
@@ -240,6 +275,7 @@ static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buff
     else
         OSI_TRY(osi_bn_eval_coeffs(buffers + b.rm_off, buffers + b.rv_off, params + b.g_off, params + b.b_off, 1e-5f, b.C,
                                    ws + b.scale, ws + b.shift, st));
+    n->mark(OSI_PROF_BN_FWD, st);
     return OSI_OK;
 }
 
@@ -250,14 +286,18 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     n->fwd_done = false;
+    n->mark(OSI_PROF_START, st);
     // stem
     OSI_TRY(osi_nchw3_to_nhwc4(image, ws + n->x4, n->B, n->H, n->W, st));
     Conv& c0 = n->convs[0];
     OSI_TRY(osi_stem_weight_pack(params + c0.w_off, ws + n->wpack, 64, st));
+    n->mark(OSI_PROF_OTHER, st);
     OSI_TRY(conv_bn_fwd(n, 0, params, buffers, ws, ws + n->x4, ws + n->wpack, training, st));
     BN& b0 = n->bns[c0.bn];
     OSI_TRY(osi_bn_apply(ws + c0.y, nullptr, ws + b0.scale, ws + b0.shift, ws + c0.a, b0.M, 64, 1, st));
+    n->mark(OSI_PROF_BN_FWD, st);
     OSI_TRY(osi_maxpool3x3s2_fwd(ws + c0.a, ws + n->a_pool, ws + n->pool_idx, n->B, n->Hs, n->Ws, 64, st));
+    n->mark(OSI_PROF_OTHER, st);
     // bottleneck blocks
     for (Block& k : n->blocks) {
         const float* x = ws + k.x_in;
@@ -269,6 +309,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
             OSI_TRY(conv_bn_fwd(n, cs[j], params, buffers, ws, in, params + c.w_off, training, st));
             if (j < 2) {
                 OSI_TRY(osi_bn_apply(ws + c.y, nullptr, ws + b.scale, ws + b.shift, ws + c.a, b.M, b.C, 1, st));
+                n->mark(OSI_PROF_BN_FWD, st);
                 in = ws + c.a;
             }
         }
@@ -279,11 +320,13 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
             OSI_TRY(conv_bn_fwd(n, k.ds, params, buffers, ws, x, params + c.w_off, training, st));
             float* xd = ws + n->scratch[0];
             OSI_TRY(osi_bn_apply(ws + c.y, nullptr, ws + b.scale, ws + b.shift, xd, b.M, b.C, 0, st));
+            n->mark(OSI_PROF_BN_FWD, st);
             res = xd;
         }
         Conv& c3 = n->convs[k.c3];
         BN& b3 = n->bns[c3.bn];
         OSI_TRY(osi_bn_apply(ws + c3.y, res, ws + b3.scale, ws + b3.shift, ws + c3.a, b3.M, b3.C, 1, st));
+        n->mark(OSI_PROF_BN_FWD, st);
     }
     // head
     const float* last = ws + n->blocks.back().out;
@@ -301,6 +344,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
         n->fwd_done = true;
         n->next_stage = 0;
     }
+    n->mark(OSI_PROF_OTHER, st);
     return OSI_OK;
 }
 
@@ -311,12 +355,14 @@ static int bn_conv_wgrad(osi_resnet50* n, int ci, const float* params, float* gr
     BN& b = n->bns[c.bn];
     OSI_TRY(osi_bn_backward(g, act, ws + c.y, ws + b.mean, ws + b.invstd, params + b.g_off, g, gmasked, grads + b.g_off,
                             grads + b.b_off, b.M, b.C, ws + n->bn_ws, n->bn_ws_bytes, st));
+    n->mark(OSI_PROF_BN_BWD, st);
     if (ci == 0) {
         OSI_TRY(osi_conv_wgrad(&c.d, g, conv_in, ws + n->gpack, ws + n->wg_ws, n->wg_ws_bytes, st));
         OSI_TRY(osi_stem_grad_unpack(ws + n->gpack, grads + c.w_off, 64, st));
     } else {
         OSI_TRY(osi_conv_wgrad(&c.d, g, conv_in, grads + c.w_off, ws + n->wg_ws, n->wg_ws_bytes, st));
     }
+    n->mark(OSI_PROF_CONV_WGRAD, st);
     return OSI_OK;
 }
 
@@ -328,6 +374,7 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     auto S = [&](int i) { return ws + n->scratch[i]; };
+    n->mark(OSI_PROF_START, st);
 
     for (int stage = stage_lo; stage < stage_hi; ++stage) {
         if (stage == 0) {
@@ -348,6 +395,7 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
                                    2048, n->F, st));
             int g = n->take();
             OSI_TRY(osi_avgpool_bwd(ws + n->dpooled, S(g), n->B, n->Hf * n->Wf, 2048, st));
+            n->mark(OSI_PROF_OTHER, st);
             n->cur_grad = g;
         }
         for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
@@ -367,8 +415,11 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
                 // downsample branch: g = dOut*(out>0) -> BN -> conv
                 OSI_TRY(osi_bn_backward(S(go), out, ws + cd.y, ws + bd.mean, ws + bd.invstd, params + bd.g_off, S(t1), nullptr,
                                         grads + bd.g_off, grads + bd.b_off, bd.M, bd.C, ws + n->bn_ws, n->bn_ws_bytes, st));
+                n->mark(OSI_PROF_BN_BWD, st);
                 OSI_TRY(osi_conv_wgrad(&cd.d, S(t1), x, grads + cd.w_off, ws + n->wg_ws, n->wg_ws_bytes, st));
+                n->mark(OSI_PROF_CONV_WGRAD, st);
                 OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dx), 0, OSI_TILE_AUTO, st));
+                n->mark(OSI_PROF_CONV_DGRAD, st);
                 n->give(t1);
                 OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, S(go), out, nullptr, ws + c2.a, st));
             } else {
@@ -378,14 +429,17 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             int t2 = n->take();
             if (t2 < 0) return OSI_ERR_STATE;
             OSI_TRY(osi_conv_dgrad(&c3.d, S(go), params + c3.w_off, S(t2), 0, OSI_TILE_AUTO, st));
+            n->mark(OSI_PROF_CONV_DGRAD, st);
             n->give(go);
             OSI_TRY(bn_conv_wgrad(n, k.c2, params, grads, ws, S(t2), ws + c2.a, nullptr, ws + c1.a, st));
             int t3 = n->take();
             if (t3 < 0) return OSI_ERR_STATE;
             OSI_TRY(osi_conv_dgrad(&c2.d, S(t2), params + c2.w_off, S(t3), 0, OSI_TILE_AUTO, st));
+            n->mark(OSI_PROF_CONV_DGRAD, st);
             n->give(t2);
             OSI_TRY(bn_conv_wgrad(n, k.c1, params, grads, ws, S(t3), ws + c1.a, nullptr, x, st));
             OSI_TRY(osi_conv_dgrad(&c1.d, S(t3), params + c1.w_off, S(dx), 1, OSI_TILE_AUTO, st));
+            n->mark(OSI_PROF_CONV_DGRAD, st);
             n->give(t3);
             n->cur_grad = dx;
         }
@@ -396,6 +450,7 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             int t = n->take();
             if (t < 0) return OSI_ERR_STATE;
             OSI_TRY(osi_maxpool3x3s2_bwd(S(go), ws + n->pool_idx, S(t), n->B, n->Hs, n->Ws, 64, st));
+            n->mark(OSI_PROF_OTHER, st);
             n->give(go);
             OSI_TRY(bn_conv_wgrad(n, 0, params, grads, ws, S(t), ws + c0.a, nullptr, ws + n->x4, st));
             n->give(t);

@@ -6,7 +6,7 @@ The library is the product: there is no CPU or eager-PyTorch fallback. Importing
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER, Structure
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER, Structure
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
@@ -56,7 +56,7 @@ _SIGS = {
     "osi_linear_bwd": (c_int, [P, P, P, P, c_int, P, P, c_int, c_int, c_int, P]),
     "osi_loss_fwd_bwd": (c_int, [c_int, P, P, c_int, c_int, c_float, c_longlong, P, P, c_int, c_float, c_float, P, P, P, P]),
     "osi_softmax": (c_int, [P, P, c_int, c_int, P]),
-    "osi_adam_step": (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_longlong, c_float, P]),
+    "osi_adam_step": (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_longlong, c_float, P]),
     "osi_sgd_step": (c_int, [P, P, P, c_size_t, c_float, c_float, c_int, c_float, P]),
     "osi_fill_f32": (c_int, [P, c_size_t, c_float, P]),
     "osi_scale_f32": (c_int, [P, c_size_t, c_float, P]),
@@ -72,6 +72,8 @@ _SIGS = {
     "osi_resnet50_workspace_bytes": (c_size_t, [c_void_p]),
     "osi_resnet50_num_stages": (c_int, [c_void_p]),
     "osi_resnet50_stage_grad_range": (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    "osi_resnet50_profile": (c_int, [c_void_p, c_int]),
+    "osi_resnet50_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int)]),
     "osi_resnet50_forward": (c_int, [c_void_p, P, P, P, P, P, P, P, c_int, P]),
     "osi_resnet50_backward": (c_int, [c_void_p, P, P, P, P, P, c_int, c_int, P]),
 }

@@ -104,8 +104,12 @@ class Adam(_FlatOptimizer):
                                       N.ptr(self._flat_state["exp_avg_sq"]), p.numel(), float(g["lr"]), float(g["betas"][0]),
                                       float(g["betas"][1]), float(g["eps"]), self._steps, float(grad_scale), N.stream_of(p)),
                 "osi_adam_step")
-        for q in m._plist:
-            self.state[q]["step"] = torch.tensor(float(self._steps))
+
+    def state_dict(self):
+        for q in self._model._plist:  # materialise torch's per-parameter step counters only when somebody looks
+            if q in self.state:
+                self.state[q]["step"] = torch.tensor(float(self._steps))
+        return super().state_dict()
 
 
 class SGD(_FlatOptimizer):

@@ -160,7 +160,7 @@ def main():
     # ---- Part 2: whole-model vectors from the oracle restatement ---------------------------------------------
     from oracle import resnet50_oracle as R, losses_oracle as L
     vec = {}
-    for tag, B, HW, C, seed in (("b2_64_c10", 2, 64, 10, 7), ("b4_96_c30", 4, 96, 30, 11)):
+    for tag, B, HW, C, seed in (("b8_128_c30", 8, 128, 30, 11), ("b16_96_c116", 16, 96, 116, 5)):
         for dt, dn in ((torch.float32, "f32"), (torch.float64, "f64")):
             gen = torch.Generator().manual_seed(seed)
             sd = R.init_state(C, C, False, generator=gen)

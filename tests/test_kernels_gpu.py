@@ -49,22 +49,24 @@ def test_conv_fwd_dgrad_wgrad(cuda, Cin, Cout, k, stride, pad, H, B):
     dw64 = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride, pad)
 
     xg, wg, dyg = T.nhwc(x).to(cuda), T.krsc(w).to(cuda), T.nhwc(dy).to(cuda)
+    # an exact-f32 fma chain of length K: error grows ~ sqrt(K) * 2^-24 relative to the output scale
+    fl = lambda K: 2e-6 + 6e-8 * K ** 0.5
     tiles = [0, 4] + ([1, 3] if Cout % 128 == 0 else []) + [2]
     for tile in tiles:
         y = T.conv_fwd(xg, wg, k, stride, pad, tile)
-        _check_vs64(T.nchw(y), y32, y64, f"conv fwd tile {tile}")
+        _check_vs64(T.nchw(y), y32, y64, f"conv fwd tile {tile}", floor=fl(Cin * k * k))
     tiles = [0, 4] + ([1, 3] if Cin % 128 == 0 else []) + [2]
     for tile in tiles:
         dx = T.conv_dgrad(dyg, wg, H, H, k, stride, pad, tile=tile)
         assert not torch.isnan(dx).any(), "dgrad left input-gradient elements unwritten"
-        _check_vs64(T.nchw(dx), dx32, dx64, f"conv dgrad tile {tile}")
+        _check_vs64(T.nchw(dx), dx32, dx64, f"conv dgrad tile {tile}", floor=fl(Cout * k * k))
     # accumulate mode: dx = base + dgrad
     base = torch.randn(B, H, H, Cin, generator=g)
     acc = T.conv_dgrad(dyg, wg, H, H, k, stride, pad, accumulate_into=base.to(cuda).clone())
-    _check_vs64(T.nchw(acc), dx32 + T.nchw(base), dx64 + T.nchw(base).double(), "conv dgrad accumulate")
+    _check_vs64(T.nchw(acc), dx32 + T.nchw(base), dx64 + T.nchw(base).double(), "conv dgrad accumulate", floor=fl(Cout * k * k))
     dw = T.conv_wgrad(dyg, xg, k, stride, pad)
     assert not torch.isnan(dw).any()
-    _check_vs64(T.oihw(dw), dw32, dw64, "conv wgrad")
+    _check_vs64(T.oihw(dw), dw32, dw64, "conv wgrad", floor=fl(B * y32.shape[2] * y32.shape[3]))
 
 
 def test_conv_large_m_splitk(cuda):
@@ -124,8 +126,8 @@ def test_batchnorm(cuda, B, C, H, relu, res):
     dout = torch.randn(B, C, H, H, generator=g)
 
     def ref(dt):
-        yy = y.to(dt).requires_grad_(True)
-        ga, be = gamma.to(dt).requires_grad_(True), beta.to(dt).requires_grad_(True)
+        yy = y.to(dt).clone().requires_grad_(True)
+        ga, be = gamma.to(dt).clone().requires_grad_(True), beta.to(dt).clone().requires_grad_(True)
         rm, rv = rm0.to(dt).clone(), rv0.to(dt).clone()
         o = F.batch_norm(yy, rm, rv, ga, be, True, 0.1, 1e-5)
         if res:
@@ -177,7 +179,8 @@ def test_bn_eval_coeffs(cuda):
     x = torch.randn(2, C, 5, 5, generator=g)
     ref = F.batch_norm(x, rm, rv, ga, be, False, 0.1, 1e-5)
     sc, sh = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
-    N.check(N.lib().osi_bn_eval_coeffs(N.ptr(rm.to(cuda)), N.ptr(rv.to(cuda)), N.ptr(ga.to(cuda)), N.ptr(be.to(cuda)), 1e-5, C, N.ptr(sc), N.ptr(sh), T.S()))
+    rmg, rvg, gag, beg = rm.to(cuda), rv.to(cuda), ga.to(cuda), be.to(cuda)   # keep alive: launches are asynchronous
+    N.check(N.lib().osi_bn_eval_coeffs(N.ptr(rmg), N.ptr(rvg), N.ptr(gag), N.ptr(beg), 1e-5, C, N.ptr(sc), N.ptr(sh), T.S()))
     xg = T.nhwc(x).to(cuda)
     out = torch.empty_like(xg)
     N.check(N.lib().osi_bn_apply(N.ptr(xg), None, N.ptr(sc), N.ptr(sh), N.ptr(out), 50, C, 0, T.S()))
@@ -200,7 +203,8 @@ def test_maxpool(cuda, B, C, H):
     N.check(N.lib().osi_maxpool3x3s2_fwd(N.ptr(xg), N.ptr(yg), N.ptr(idx), B, H, H, C, T.S()))
     assert torch.equal(T.nchw(yg).cpu(), y.detach())
     dx = torch.empty_like(xg)
-    N.check(N.lib().osi_maxpool3x3s2_bwd(N.ptr(T.nhwc(dy).to(cuda)), N.ptr(idx), N.ptr(dx), B, H, H, C, T.S()))
+    dyg = T.nhwc(dy).to(cuda)
+    N.check(N.lib().osi_maxpool3x3s2_bwd(N.ptr(dyg), N.ptr(idx), N.ptr(dx), B, H, H, C, T.S()))
     assert torch.allclose(T.nchw(dx).cpu(), x.grad, atol=1e-6), "maxpool backward (first-max tie rule)"
 
 
@@ -217,7 +221,8 @@ def test_avgpool(cuda):
     N.check(N.lib().osi_avgpool_fwd(N.ptr(xg), N.ptr(yg), 3, 49, 2048, T.S()))
     assert torch.allclose(yg.cpu(), y.detach(), atol=1e-6)
     dx = torch.empty_like(xg)
-    N.check(N.lib().osi_avgpool_bwd(N.ptr(dy.to(cuda)), N.ptr(dx), 3, 49, 2048, T.S()))
+    dyg = dy.to(cuda)
+    N.check(N.lib().osi_avgpool_bwd(N.ptr(dyg), N.ptr(dx), 3, 49, 2048, T.S()))
     assert torch.allclose(T.nchw(dx).cpu(), x.grad, atol=1e-7)
 
 
@@ -230,7 +235,7 @@ def test_linear(cuda, B, K, O, bias):
     dy = torch.randn(B, O, generator=g)
 
     def ref(dt):
-        xx, ww, bb = x.to(dt).requires_grad_(True), w.to(dt).requires_grad_(True), b.to(dt).requires_grad_(True)
+        xx, ww, bb = (t.to(dt).clone().requires_grad_(True) for t in (x, w, b))
         y = F.linear(xx, ww, bb if bias else None)
         y.backward(dy.to(dt))
         return y.detach(), xx.grad, ww.grad, bb.grad if bias else None
@@ -277,7 +282,9 @@ def test_losses_vs_reference_golden(cuda, golden_dir):
                 assert torch.isnan(loss), f"{p}: all-ignored batch must give NaN like torch"
                 continue
             assert abs(float(loss) - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss)), f"{p} loss {float(loss)} vs {ref_loss}"
-            assert float((dz - ref_dz).abs().max()) <= 2e-7 + 1e-6 * float(ref_dz.abs().max()), f"{p} dlogits"
+            # expf(x) carries ~|x| ulp of relative error: scale the bound with the logit range
+            tol = 2e-7 + 1e-6 * float(ref_dz.abs().max()) + 2e-8 * float(z.abs().max())
+            assert float((dz - ref_dz).abs().max()) <= tol, f"{p} dlogits"
             loss2, _, _ = _run_loss(cuda, mode, z, y, w, cw, want_grad=False)
             assert torch.equal(loss, loss2), "loss-only launch must give the same bits"
 
@@ -306,7 +313,8 @@ def test_softmax_kernel(cuda):
     import osi_testlib as T
     z = torch.randn(37, 151) * 4
     out = torch.empty(37, 151, device=cuda)
-    N.check(N.lib().osi_softmax(N.ptr(z.to(cuda)), N.ptr(out), 37, 151, T.S()))
+    zg = z.to(cuda)
+    N.check(N.lib().osi_softmax(N.ptr(zg), N.ptr(out), 37, 151, T.S()))
     assert torch.allclose(out.cpu(), torch.softmax(z, 1), atol=1e-7, rtol=1e-5)
 
 
