@@ -142,6 +142,10 @@ int osi_resnet50_forward(osi_resnet50_t net, const float* params, float* buffers
 int osi_resnet50_backward(osi_resnet50_t net, const float* params, float* grads, void* workspace, const float* dlogits,
                           const float* dfeatures, int stage_lo, int stage_hi, osi_stream_t stream);
 
+/* Weight gradients on a low-priority side stream, overlapped with dgrad / BatchNorm backward (default on; joined back into
+ * `stream` at the end of every backward stage). enable = 0 serialises everything on the caller's stream. */
+int osi_resnet50_set_overlap(osi_resnet50_t net, int enable);
+
 /* Optional HIP-event instrumentation of the executor (bench.py's roofline leg): one event after every op on the launch
  * stream, attributed to a kernel class. profile_read synchronises on the last event — call it outside timed regions. */
 enum { OSI_PROF_START = 0, OSI_PROF_CONV_FWD = 1, OSI_PROF_CONV_DGRAD = 2, OSI_PROF_CONV_WGRAD = 3, OSI_PROF_BN_FWD = 4,

@@ -26,8 +26,10 @@ __host__ __device__ inline RowSplit row_split(int C) {
 }
 
 // ---- statistics -------------------------------------------------------------------------------------
+// partials are stored channel-major ([C][P]) so that the finalising wave of a channel reads them coalesced
 __global__ __launch_bounds__(NT) void k_bn_stats_partial(const float* __restrict__ y, int M, int C, int rows_per_blk,
                                                         float* __restrict__ pmean, float* __restrict__ pm2) {
+    const int P = gridDim.x;
     __shared__ f32x4 red[2][NT];
     const RowSplit sp = row_split(C);
     const int tid = threadIdx.x;
@@ -63,53 +65,48 @@ __global__ __launch_bounds__(NT) void k_bn_stats_partial(const float* __restrict
             for (int k = 1; k < sp.RL; ++k) { s1 += red[0][k * sp.CV + cv]; s2 += red[1][k * sp.CV + cv]; }
             f32x4 mean = shift + s1 / n;
             f32x4 m2 = s2 - s1 * s1 / n;
-            reinterpret_cast<f32x4*>(pmean + (size_t)blockIdx.x * C)[c4] = mean;
-            reinterpret_cast<f32x4*>(pm2 + (size_t)blockIdx.x * C)[c4] = m2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pmean[(size_t)(c4 * 4 + k) * P + blockIdx.x] = mean[k];
+                pm2[(size_t)(c4 * 4 + k) * P + blockIdx.x] = m2[k];
+            }
         }
         __syncthreads();
     }
 }
 
-// One workgroup = 32 channels x 8 partial lanes. mean = sum n_b mean_b / M ; M2 = sum M2_b + n_b (mean_b-mean)^2
+// One wave per channel: every lane Chan-merges its share of the P per-workgroup (n, mean, M2) triples in a fixed order,
+// then a fixed xor-shuffle tree merges the 64 lanes. Deterministic, single pass over the partials.
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& sa, float nb, float mb, float sb) {
+    if (nb == 0.f) return;
+    if (na == 0.f) { na = nb; ma = mb; sa = sb; return; }
+    const float n = na + nb, d = mb - ma;
+    ma += d * (nb / n);
+    sa += sb + d * d * (na * nb / n);
+    na = n;
+}
 __global__ __launch_bounds__(NT) void k_bn_stats_final(const float* __restrict__ pmean, const float* __restrict__ pm2, int P,
                                                       int rows_per_blk, int M, int C, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float momentum,
                                                       float* running_mean, float* running_var, float* __restrict__ mean_out,
                                                       float* __restrict__ invstd_out, float* __restrict__ scale_out,
                                                       float* __restrict__ shift_out) {
-    __shared__ float red[8][32];
-    __shared__ float smean[32];
-    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    const bool ok = c < C;
-    float acc = 0.f;
-    if (ok)
-        for (int b = pl; b < P; b += 8) {
-            float nb = (float)min(rows_per_blk, M - b * rows_per_blk);
-            acc += nb * pmean[(size_t)b * C + c];
-        }
-    red[pl][cl] = acc;
-    __syncthreads();
-    if (pl == 0) {
-        float s = 0.f;
-        for (int k = 0; k < 8; ++k) s += red[k][cl];
-        smean[cl] = s / (float)M;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int b = lane; b < P; b += 64) {
+        const float nb = (float)min(rows_per_blk, M - b * rows_per_blk);
+        chan_merge(n, mean, m2, nb, pmean[(size_t)c * P + b], pm2[(size_t)c * P + b]);
     }
-    __syncthreads();
-    const float mean = smean[cl];
-    acc = 0.f;
-    if (ok)
-        for (int b = pl; b < P; b += 8) {
-            float nb = (float)min(rows_per_blk, M - b * rows_per_blk);
-            float d = pmean[(size_t)b * C + c] - mean;
-            acc += pm2[(size_t)b * C + c] + nb * d * d;
-        }
-    __syncthreads();
-    red[pl][cl] = acc;
-    __syncthreads();
-    if (pl == 0 && ok) {
-        float m2 = 0.f;
-        for (int k = 0; k < 8; ++k) m2 += red[k][cl];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), sb = __shfl_xor(m2, o, 64);
+        // both partners must compute the identical merge: order the pair by lane parity at this level
+        if (lane & o) { float na = nb, ma = mb, sa = sb; chan_merge(na, ma, sa, n, mean, m2); n = na; mean = ma; m2 = sa; }
+        else chan_merge(n, mean, m2, nb, mb, sb);
+    }
+    if (lane == 0) {
         float var = m2 / (float)M;
         float invstd = 1.0f / sqrtf(var + eps);
         mean_out[c] = mean; invstd_out[c] = invstd;
@@ -155,6 +152,7 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float* __restrict__
                                                       const float* __restrict__ invstd, int M, int C, int rows_per_blk,
                                                       float* __restrict__ pdb, float* __restrict__ pdg) {
     __shared__ f32x4 red[2][NT];
+    const int P = gridDim.x;
     const RowSplit sp = row_split(C);
     const int tid = threadIdx.x;
     const int cv = tid % sp.CV, rl = tid / sp.CV;
@@ -187,8 +185,11 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float* __restrict__
         __syncthreads();
         if (colok && rl == 0) {
             for (int k = 1; k < sp.RL; ++k) { sb += red[0][k * sp.CV + cv]; sg += red[1][k * sp.CV + cv]; }
-            reinterpret_cast<f32x4*>(pdb + (size_t)blockIdx.x * C)[c4] = sb;
-            reinterpret_cast<f32x4*>(pdg + (size_t)blockIdx.x * C)[c4] = sg;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pdb[(size_t)(c4 * 4 + k) * P + blockIdx.x] = sb[k];
+                pdg[(size_t)(c4 * 4 + k) * P + blockIdx.x] = sg[k];
+            }
         }
         __syncthreads();
     }
@@ -197,19 +198,15 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float* __restrict__
 __global__ __launch_bounds__(NT) void k_bn_bwd_final(const float* __restrict__ pdb, const float* __restrict__ pdg, int P, int M,
                                                     int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                     float* __restrict__ c1, float* __restrict__ c2) {
-    __shared__ float red[2][8][32];
-    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (c >= C) return;
     float ab = 0.f, ag = 0.f;
-    if (c < C)
-        for (int b = pl; b < P; b += 8) { ab += pdb[(size_t)b * C + c]; ag += pdg[(size_t)b * C + c]; }
-    red[0][pl][cl] = ab; red[1][pl][cl] = ag;
-    __syncthreads();
-    if (pl == 0 && c < C) {
-        float sb = 0.f, sg = 0.f;
-        for (int k = 0; k < 8; ++k) { sb += red[0][k][cl]; sg += red[1][k][cl]; }
-        dbeta[c] = sb; dgamma[c] = sg;
-        c1[c] = sb / (float)M; c2[c] = sg / (float)M;
+    for (int b = lane; b < P; b += 64) { ab += pdb[(size_t)c * P + b]; ag += pdg[(size_t)c * P + b]; }
+    ab = wave_sum(ab); ag = wave_sum(ag);
+    if (lane == 0) {
+        dbeta[c] = ab; dgamma[c] = ag;
+        c1[c] = ab / (float)M; c2[c] = ag / (float)M;
     }
 }
 
@@ -248,9 +245,11 @@ static int rows_per_block(int M, int C, int& P) {
     P = (int)((M + rows - 1) / rows);
     return (int)rows;
 }
+// 4 workgroups (16 waves) per CU stream at the HBM rate and leave half of every CU's wave slots, and all of its LDS, to the
+// weight-gradient kernels that run concurrently on the executor's side stream.
 static int stream_grid(size_t n4) {
     size_t g = (n4 + NT - 1) / NT;
-    return (int)(g > 2048 ? 2048 : g);
+    return (int)(g > 1024 ? 1024 : g);
 }
 
 }  // namespace
@@ -278,7 +277,7 @@ int osi_bn_train_stats(const float* y, int M, int C, const float* gamma, const f
     float* pm2 = pmean + (size_t)P * C;
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(P), dim3(NT), 0, st, y, M, C, rpb, pmean, pm2);
     OSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_stats_final, dim3(osi_cdiv(C, 32)), dim3(NT), 0, st, pmean, pm2, P, rpb, M, C, gamma, beta, eps,
+    hipLaunchKernelGGL(k_bn_stats_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, pmean, pm2, P, rpb, M, C, gamma, beta, eps,
                        momentum, running_mean, running_var, mean, invstd, scale, shift);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
@@ -326,7 +325,7 @@ int osi_bn_backward(const float* dout, const float* act, const float* y, const f
     float* c2 = c1 + C;
     hipLaunchKernelGGL(k_bn_bwd_partial, dim3(P), dim3(NT), 0, st, dout, act, y, mean, invstd, M, C, rpb, pdb, pdg);
     OSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, 32)), dim3(NT), 0, st, pdb, pdg, P, M, C, dgamma, dbeta, c1, c2);
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, pdb, pdg, P, M, C, dgamma, dbeta, c1, c2);
     OSI_LAUNCH_CHECK();
     const size_t n4 = (size_t)M * C / 4;
     const int grid = stream_grid(n4), c4n = C / 4;

@@ -38,7 +38,9 @@ struct ConvP {
     int Ktot;         // R*S*Cin (row length of W)
     int MT, NT;       // tile counts
     int accumulate;   // epilogue adds into y
-    FastDiv dHoWo, dWo;  // fwd/wgrad: divide by Ho*Wo, Wo ; dgrad: by Hc*Wc, Wc of the class grid
+    FastDiv dHoWo, dWo;  // fwd/wgrad: divide by Ho*Wo, Wo
+    FastDiv cHW[4], cW[4];  // dgrad: Hc*Wc and Wc of each parity class grid (stride <= 2)
+    int unit;             // dgrad: 1x1 stride-1 conv -> the im2col row of pixel m is row m of dY
     // wgrad only
     int kchunk;       // pixels per split
     size_t slab_stride;
@@ -269,19 +271,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0
     const int nR = rb < p.R ? (p.R - rb + st - 1) / st : 0;
     const int nS = sb < p.S ? (p.S - sb + st - 1) / st : 0;
 
+    const FastDiv dHW = p.cHW[cls], dW = p.cW[cls];
     int a_base[AR], a_hb[AR], a_wb[AR];
     bool a_ok[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int m = m0 + lr + 32 * i;
         a_ok[i] = m < Mc;
-        int mm = a_ok[i] ? m : 0;
-        int b = mm / (Hc * Wc);
-        int rem = mm - b * Hc * Wc;
-        int h2 = rem / Wc, w2 = rem - h2 * Wc;
-        a_base[i] = b * p.Ho * p.Wo * p.Cout;
-        a_hb[i] = (ph + st * h2 + p.pad - rb) / st;
-        a_wb[i] = (pw + st * w2 + p.pad - sb) / st;
+        uint32_t mm = a_ok[i] ? (uint32_t)m : 0u;
+        if (p.unit) {  // dY row = pixel index, never out of bounds
+            a_base[i] = (int)mm * p.Cout; a_hb[i] = 0; a_wb[i] = 0;
+        } else {
+            uint32_t b = fdiv(mm, dHW);
+            uint32_t rem = mm - b * dHW.d;
+            uint32_t h2 = fdiv(rem, dW), w2 = rem - h2 * dW.d;
+            a_base[i] = (int)b * p.Ho * p.Wo * p.Cout;
+            a_hb[i] = (ph + st * (int)h2 + p.pad - rb) / st;
+            a_wb[i] = (pw + st * (int)w2 + p.pad - sb) / st;
+        }
     }
     (void)Hc0; (void)Wc0;
 
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             int ho = a_hb[i] - jr, wo = a_wb[i] - js;
-            bool ok = a_ok[i] && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
+            bool ok = a_ok[i] && (p.unit || ((unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo));
             int off = ok ? a_base[i] + (ho * p.Wo + wo) * p.Cout + c0 + kq * 4 : 0;
             f32x4 v = ld4(p.x + off);
             ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -343,24 +350,40 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0
         }
     }
 
+    // epilogue: all destination rows of a 32x32 tile are addressed first, (accumulate: loaded in one batch), then stored
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i) {
+        size_t rowoff[16];
+        bool rowok[16];
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             int m = m0 + wm * 32 * WM + i * 32 + acc_row(rr, lane);
-            if (m < Mc) {
-                int b = m / (Hc * Wc);
-                int rem = m - b * Hc * Wc;
-                int h2 = rem / Wc, w2 = rem - h2 * Wc;
-                size_t pix = ((size_t)b * p.H + (ph + st * h2)) * p.W + (pw + st * w2);
-#pragma unroll
-                for (int n = 0; n < WN; ++n) {
-                    const int col = n0 + wn * 32 * WN + n * 32 + (lane & 31);
-                    float* dst = p.y + pix * p.Cin + col;
-                    *dst = p.accumulate ? *dst + acc[i][n][rr] : acc[i][n][rr];
-                }
+            rowok[rr] = m < Mc;
+            uint32_t mm = rowok[rr] ? (uint32_t)m : 0u;
+            size_t pix;
+            if (st == 1) pix = mm;
+            else {
+                uint32_t b = fdiv(mm, dHW);
+                uint32_t rem = mm - b * dHW.d;
+                uint32_t h2 = fdiv(rem, dW), w2 = rem - h2 * dW.d;
+                pix = ((size_t)b * p.H + (ph + st * (int)h2)) * p.W + (pw + st * (int)w2);
             }
+            rowoff[rr] = pix * p.Cin;
         }
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int col = n0 + wn * 32 * WN + n * 32 + (lane & 31);
+            if (p.accumulate) {
+                f32x16 old;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) old[rr] = rowok[rr] ? p.y[rowoff[rr] + col] : 0.f;
+                acc[i][n] += old;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr)
+                if (rowok[rr]) p.y[rowoff[rr] + col] = acc[i][n][rr];
+        }
+    }
 }
 
 // ======================================================================================================
@@ -474,13 +497,28 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(ConvP p) {
 }
 
 // out[i] = sum_s slab[s][i]  (fixed order: bitwise reproducible)
+// One workgroup = 16 consecutive float4 outputs x 16 split lanes: lane j sums splits j, j+16, ... (4 independent loads in
+// flight), then the 16 lane partials are added in lane order. Many small dependent-latency chains instead of one long one.
 __global__ __launch_bounds__(256) void k_slab_reduce(const float* slab, float* out, size_t n4, size_t stride4, int splits) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t step = (size_t)gridDim.x * blockDim.x;
+    __shared__ f32x4 red[16][16];
+    const int o = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + o;
     const f32x4* s = reinterpret_cast<const f32x4*>(slab);
-    for (; i < n4; i += step) {
-        f32x4 a = s[i];
-        for (int k = 1; k < splits; ++k) a += s[i + k * stride4];
+    f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    if (i < n4) {
+        int k = l;
+        for (; k + 48 < splits; k += 64) {
+            a0 += s[i + (size_t)k * stride4]; a1 += s[i + (size_t)(k + 16) * stride4];
+            a2 += s[i + (size_t)(k + 32) * stride4]; a3 += s[i + (size_t)(k + 48) * stride4];
+        }
+        for (; k < splits; k += 16) a0 += s[i + (size_t)k * stride4];
+    }
+    red[l][o] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (l == 0 && i < n4) {
+        f32x4 a = red[0][o];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) a += red[k][o];
         reinterpret_cast<f32x4*>(out)[i] = a;
     }
 }
@@ -548,6 +586,13 @@ template <int WM, int WN>
 static int launch_dgrad(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int s = p.stride;
+    for (int ph = 0; ph < s; ++ph)
+        for (int pw = 0; pw < s; ++pw) {
+            const int hc = (p.H - ph + s - 1) / s, wc = (p.W - pw + s - 1) / s;
+            p.cHW[ph * s + pw] = make_fastdiv((uint32_t)(hc * wc > 0 ? hc * wc : 1));
+            p.cW[ph * s + pw] = make_fastdiv((uint32_t)(wc > 0 ? wc : 1));
+        }
+    p.unit = (p.R == 1 && p.S == 1 && s == 1 && p.pad == 0) ? 1 : 0;
     const int Hc = osi_cdiv(p.H, s), Wc = osi_cdiv(p.W, s);  // largest class
     p.MT = osi_cdiv((long)p.B * Hc * Wc, BM); p.NT = p.Cin / BN;
     size_t smem = 2 * (size_t)(BM * LDR + BK * (BN + 4)) * sizeof(float);
@@ -581,7 +626,7 @@ static WgradPlan plan_wgrad(const osi_conv_desc* d) {
     const long tiles = (long)(d->Cout / BMg) * (stem ? osi_cdiv(Ktot, BNg) : d->R * d->S * (d->Cin / BNg));
     const long M = (long)d->B * d->Ho * d->Wo;
     long splits = (1024 + tiles - 1) / tiles;               // aim at ~4 workgroups per CU
-    long maxs = (M + 4 * BK - 1) / (4 * BK);                // at least 4 K tiles per split
+    long maxs = (M + 8 * BK - 1) / (8 * BK);                // at least 8 K tiles per split (amortises the 64 KiB slab tile)
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
     long chunk = ((M + splits - 1) / splits + BK - 1) / BK * BK;
@@ -605,11 +650,11 @@ int osi_conv_fwd(const osi_conv_desc* d, const float* x, const float* w, float* 
     }
     OSI_REQUIRE(d->Cin % BK == 0 && d->Cout % 64 == 0);
     if (tile == OSI_TILE_AUTO) {
-        const long M = p.M;
-        if (d->Cout % 128 == 0 && (M / 128) * (d->Cout / 128) >= 384) tile = OSI_TILE_128x128;
-        else if ((M / 128) * (d->Cout / 64) >= 384) tile = OSI_TILE_128x64;
-        else if (d->Cout % 128 == 0 && (M / 64) * (d->Cout / 128) >= 256) tile = OSI_TILE_64x128;
-        else tile = OSI_TILE_64x64;
+        // Measured on MI355X over the 22 ResNet-50 shapes at B=128 (tools/bench_conv.py, profiles/conv_layers_r01.txt): many
+        // small workgroups (4 resident per CU) beat large tiles almost everywhere because the ragged last round of the launch is
+        // shorter; only the 7x7-spatial layers with few column tiles prefer the wider 64x128 tile.
+        const long tiles64 = ((long)p.M + 63) / 64 * (d->Cout / 64);
+        tile = (tiles64 < 1024 && d->Cout % 128 == 0) ? OSI_TILE_64x128 : OSI_TILE_64x64;
     }
     switch (tile) {
         case OSI_TILE_128x128: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<2, 2, false>(p, st);
@@ -624,17 +669,12 @@ int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, floa
                    osi_stream_t stream) {
     OSI_REQUIRE(desc_ok(d) && dy && w && dx);
     OSI_REQUIRE(!is_stem(d));  // the image needs no gradient (train.py:128-139: input is a leaf without grad)
-    OSI_REQUIRE(d->Cout % BK == 0 && d->Cin % 64 == 0);
+    OSI_REQUIRE(d->Cout % BK == 0 && d->Cin % 64 == 0 && d->stride <= 2);
     hipStream_t st = (hipStream_t)stream;
     ConvP p = make_p(d);
     p.x = dy; p.w = w; p.y = dx; p.accumulate = accumulate;
-    if (tile == OSI_TILE_AUTO) {
-        const long M = (long)d->B * d->H * d->W;
-        if (d->Cin % 128 == 0 && (M / 128) * (d->Cin / 128) >= 384) tile = OSI_TILE_128x128;
-        else if ((M / 128) * (d->Cin / 64) >= 384) tile = OSI_TILE_128x64;
-        else if (d->Cin % 128 == 0 && (M / 64) * (d->Cin / 128) >= 256) tile = OSI_TILE_64x128;
-        else tile = OSI_TILE_64x64;
-    }
+    if (tile == OSI_TILE_AUTO)  // measured (see osi_conv_fwd): 64 rows x the widest column tile the input channels allow
+        tile = d->Cin % 128 == 0 ? OSI_TILE_64x128 : OSI_TILE_64x64;
     switch (tile) {
         case OSI_TILE_128x128: OSI_REQUIRE(d->Cin % 128 == 0); return launch_dgrad<2, 2>(p, st);
         case OSI_TILE_128x64: return launch_dgrad<2, 1>(p, st);
@@ -673,8 +713,7 @@ int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, floa
     if (e) return e;
     if (w.splits > 1) {
         size_t n4 = n / 4;
-        int grid = (int)((n4 + 255) / 256); if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(k_slab_reduce, dim3(grid), dim3(256), 0, st, (const float*)ws, dw, n4, n4, w.splits);
+        hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)ws, dw, n4, n4, w.splits);
         OSI_LAUNCH_CHECK();
     }
     return OSI_OK;

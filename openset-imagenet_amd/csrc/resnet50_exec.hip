@@ -12,6 +12,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 
 #define OSI_TRY(x)                 \
     do {                           \
@@ -65,7 +66,8 @@ struct osi_resnet50 {
     int Hs, Ws, Hp, Wp;              // stem conv output, maxpool output
     size_t x4, wpack, gpack, a_pool, pool_idx, pooled, feat, logits_ws;
     size_t bn_ws, bn_ws_bytes, wg_ws, wg_ws_bytes;
-    size_t scratch[6], scratch_floats;
+    static constexpr int NSCR = 12;   // scratch activations-gradient buffers (each = largest activation)
+    size_t scratch[NSCR], scratch_floats;
     size_t dfeat, dpooled;
     int Hf, Wf;                      // final spatial size
     // stage bookkeeping
@@ -124,11 +126,55 @@ struct osi_resnet50 {
         convs.push_back(c);
         return (int)convs.size() - 1;
     }
-    int take() {
+    // Weight gradients run on a low-priority side stream: they are off the critical path of backward (nothing downstream
+    // reads them before the optimizer) and fill the matrix pipes while the main stream is in HBM-bound BatchNorm kernels
+    // or in the ragged last round of a dgrad launch. buf_ev[i] = last side-stream reader of scratch buffer i.
+    bool overlap = true;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t buf_ev[NSCR] = {};
+    bool buf_pending[NSCR] = {};
+    bool side_dirty = false;
+    int ensure_side() {
+        if (side) return OSI_OK;
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return OSI_ERR_LAUNCH;
+        const char* pr = getenv("OSI_SIDE_PRIO");  // dev A/B switch: "normal" gives the side stream the default priority
+        const int prio = (pr && pr[0] == 'n') ? 0 : lo;
+        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
+        for (int i = 0; i < NSCR; ++i)
+            if (hipEventCreateWithFlags(&buf_ev[i], hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
+        return OSI_OK;
+    }
+    bool async_wgrad() const { return overlap && !prof_on && side != nullptr; }
+    // a scratch buffer may only be rewritten on `st` after its last side-stream reader has finished
+    int take(hipStream_t st) {
         if (free_list.empty()) return -1;
-        int i = free_list.back(); free_list.pop_back(); return i;
+        // FIFO: hand out the buffer that was released longest ago, so its side-stream reader has most likely finished
+        int i = free_list.front(); free_list.erase(free_list.begin());
+        if (buf_pending[i]) { (void)hipStreamWaitEvent(st, buf_ev[i], 0); buf_pending[i] = false; }
+        return i;
     }
     void give(int i) { free_list.push_back(i); }
+    int join_side(hipStream_t st) {
+        if (!side_dirty) return OSI_OK;
+        if (hipEventRecord(ev_join, side) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+        for (int i = 0; i < NSCR; ++i) buf_pending[i] = false;
+        side_dirty = false;
+        return OSI_OK;
+    }
+    ~osi_resnet50() {
+        for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
+        if (side) {
+            (void)hipStreamSynchronize(side);
+            (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join);
+            for (int i = 0; i < NSCR; ++i) (void)hipEventDestroy(buf_ev[i]);
+            (void)hipStreamDestroy(side);
+        }
+    }
 };
 
 extern "C" {
@@ -200,7 +246,7 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
     n->bn_ws_bytes = bnws; n->bn_ws = n->ws_alloc(bnws / 4 + 4);
     n->wg_ws_bytes = wgws; n->wg_ws = n->ws_alloc(wgws / 4 + 4);
     n->scratch_floats = maxact;
-    for (int i = 0; i < 6; ++i) n->scratch[i] = n->ws_alloc(maxact);
+    for (int i = 0; i < osi_resnet50::NSCR; ++i) n->scratch[i] = n->ws_alloc(maxact);
     *out = n;
     return OSI_OK;
 }
@@ -348,22 +394,42 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     return OSI_OK;
 }
 
-// backward of conv+BN(+ReLU mask): dout (in scratch `g`) -> dy in place, then wgrad; returns with dy still in `g`
-static int bn_conv_wgrad(osi_resnet50* n, int ci, const float* params, float* grads, float* ws, float* g, const float* act,
-                         float* gmasked, const float* conv_in, hipStream_t st) {
+// weight gradient of conv `ci` from dy (scratch buffer index gi): on the side stream when overlap is on
+static int wgrad(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const float* conv_in, hipStream_t st) {
     Conv& c = n->convs[ci];
-    BN& b = n->bns[c.bn];
-    OSI_TRY(osi_bn_backward(g, act, ws + c.y, ws + b.mean, ws + b.invstd, params + b.g_off, g, gmasked, grads + b.g_off,
-                            grads + b.b_off, b.M, b.C, ws + n->bn_ws, n->bn_ws_bytes, st));
-    n->mark(OSI_PROF_BN_BWD, st);
+    const float* dy = ws + n->scratch[gi];
+    hipStream_t ws_st = st;
+    const bool async = n->async_wgrad();
+    if (async) {
+        if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+        ws_st = n->side;
+    }
     if (ci == 0) {
-        OSI_TRY(osi_conv_wgrad(&c.d, g, conv_in, ws + n->gpack, ws + n->wg_ws, n->wg_ws_bytes, st));
-        OSI_TRY(osi_stem_grad_unpack(ws + n->gpack, grads + c.w_off, 64, st));
+        OSI_TRY(osi_conv_wgrad(&c.d, dy, conv_in, ws + n->gpack, ws + n->wg_ws, n->wg_ws_bytes, ws_st));
+        OSI_TRY(osi_stem_grad_unpack(ws + n->gpack, grads + c.w_off, 64, ws_st));
     } else {
-        OSI_TRY(osi_conv_wgrad(&c.d, g, conv_in, grads + c.w_off, ws + n->wg_ws, n->wg_ws_bytes, st));
+        OSI_TRY(osi_conv_wgrad(&c.d, dy, conv_in, grads + c.w_off, ws + n->wg_ws, n->wg_ws_bytes, ws_st));
+    }
+    if (async) {
+        if (hipEventRecord(n->buf_ev[gi], n->side) != hipSuccess) return OSI_ERR_LAUNCH;
+        n->buf_pending[gi] = true;
+        n->side_dirty = true;
     }
     n->mark(OSI_PROF_CONV_WGRAD, st);
     return OSI_OK;
+}
+
+// backward of conv+BN(+ReLU mask): dout (in scratch buffer gi) -> dy in place, then wgrad; returns with dy still in the buffer
+static int bn_conv_wgrad(osi_resnet50* n, int ci, const float* params, float* grads, float* ws, int gi, const float* act,
+                         float* gmasked, const float* conv_in, hipStream_t st) {
+    Conv& c = n->convs[ci];
+    BN& b = n->bns[c.bn];
+    float* g = ws + n->scratch[gi];
+    OSI_TRY(osi_bn_backward(g, act, ws + c.y, ws + b.mean, ws + b.invstd, params + b.g_off, g, gmasked, grads + b.g_off,
+                            grads + b.b_off, b.M, b.C, ws + n->bn_ws, n->bn_ws_bytes, st));
+    n->mark(OSI_PROF_BN_BWD, st);
+    return wgrad(n, ci, grads, ws, gi, conv_in, st);
 }
 
 int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, void* workspace, const float* dlogits,
@@ -374,13 +440,14 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     auto S = [&](int i) { return ws + n->scratch[i]; };
+    if (n->overlap && !n->prof_on) OSI_TRY(n->ensure_side());
     n->mark(OSI_PROF_START, st);
 
     for (int stage = stage_lo; stage < stage_hi; ++stage) {
         if (stage == 0) {
             OSI_REQUIRE(dlogits);
             n->free_list.clear();
-            for (int i = 5; i >= 0; --i) n->free_list.push_back(i);
+            for (int i = 0; i < osi_resnet50::NSCR; ++i) { n->free_list.push_back(i); n->buf_pending[i] = false; }
             const Tensor& fw = n->tensors[n->t_fc_w]; const Tensor& fb = n->tensors[n->t_fc_b]; const Tensor& lw = n->tensors[n->t_lg_w];
             float* dfeat = ws + n->dfeat;
             int acc = 0;
@@ -393,7 +460,7 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             OSI_TRY(osi_linear_bwd(dlogits, ws + n->feat, params + lw.off, dfeat, acc, grads + lw.off, dlb, n->B, n->F, n->O, st));
             OSI_TRY(osi_linear_bwd(dfeat, ws + n->pooled, params + fw.off, ws + n->dpooled, 0, grads + fw.off, grads + fb.off, n->B,
                                    2048, n->F, st));
-            int g = n->take();
+            int g = n->take(st);
             OSI_TRY(osi_avgpool_bwd(ws + n->dpooled, S(g), n->B, n->Hf * n->Wf, 2048, st));
             n->mark(OSI_PROF_OTHER, st);
             n->cur_grad = g;
@@ -405,39 +472,38 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             const float* x = ws + k.x_in;
             const float* out = ws + k.out;
             Conv &c1 = n->convs[k.c1], &c2 = n->convs[k.c2], &c3 = n->convs[k.c3];
-            int dx = n->take();
+            int dx = n->take(st);
             if (dx < 0) return OSI_ERR_STATE;
             if (k.ds >= 0) {
                 Conv& cd = n->convs[k.ds];
                 BN& bd = n->bns[cd.bn];
-                int t1 = n->take();
+                int t1 = n->take(st);
                 if (t1 < 0) return OSI_ERR_STATE;
                 // downsample branch: g = dOut*(out>0) -> BN -> conv
                 OSI_TRY(osi_bn_backward(S(go), out, ws + cd.y, ws + bd.mean, ws + bd.invstd, params + bd.g_off, S(t1), nullptr,
                                         grads + bd.g_off, grads + bd.b_off, bd.M, bd.C, ws + n->bn_ws, n->bn_ws_bytes, st));
                 n->mark(OSI_PROF_BN_BWD, st);
-                OSI_TRY(osi_conv_wgrad(&cd.d, S(t1), x, grads + cd.w_off, ws + n->wg_ws, n->wg_ws_bytes, st));
-                n->mark(OSI_PROF_CONV_WGRAD, st);
+                OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
                 OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dx), 0, OSI_TILE_AUTO, st));
                 n->mark(OSI_PROF_CONV_DGRAD, st);
                 n->give(t1);
-                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, S(go), out, nullptr, ws + c2.a, st));
+                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, go, out, nullptr, ws + c2.a, st));
             } else {
                 // identity skip: the masked gradient itself continues to the block input
-                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, S(go), out, S(dx), ws + c2.a, st));
+                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, go, out, S(dx), ws + c2.a, st));
             }
-            int t2 = n->take();
+            int t2 = n->take(st);
             if (t2 < 0) return OSI_ERR_STATE;
             OSI_TRY(osi_conv_dgrad(&c3.d, S(go), params + c3.w_off, S(t2), 0, OSI_TILE_AUTO, st));
             n->mark(OSI_PROF_CONV_DGRAD, st);
             n->give(go);
-            OSI_TRY(bn_conv_wgrad(n, k.c2, params, grads, ws, S(t2), ws + c2.a, nullptr, ws + c1.a, st));
-            int t3 = n->take();
+            OSI_TRY(bn_conv_wgrad(n, k.c2, params, grads, ws, t2, ws + c2.a, nullptr, ws + c1.a, st));
+            int t3 = n->take(st);
             if (t3 < 0) return OSI_ERR_STATE;
             OSI_TRY(osi_conv_dgrad(&c2.d, S(t2), params + c2.w_off, S(t3), 0, OSI_TILE_AUTO, st));
             n->mark(OSI_PROF_CONV_DGRAD, st);
             n->give(t2);
-            OSI_TRY(bn_conv_wgrad(n, k.c1, params, grads, ws, S(t3), ws + c1.a, nullptr, x, st));
+            OSI_TRY(bn_conv_wgrad(n, k.c1, params, grads, ws, t3, ws + c1.a, nullptr, x, st));
             OSI_TRY(osi_conv_dgrad(&c1.d, S(t3), params + c1.w_off, S(dx), 1, OSI_TILE_AUTO, st));
             n->mark(OSI_PROF_CONV_DGRAD, st);
             n->give(t3);
@@ -447,18 +513,26 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             // maxpool + stem
             Conv& c0 = n->convs[0];
             int go = n->cur_grad;
-            int t = n->take();
+            int t = n->take(st);
             if (t < 0) return OSI_ERR_STATE;
             OSI_TRY(osi_maxpool3x3s2_bwd(S(go), ws + n->pool_idx, S(t), n->B, n->Hs, n->Ws, 64, st));
             n->mark(OSI_PROF_OTHER, st);
             n->give(go);
-            OSI_TRY(bn_conv_wgrad(n, 0, params, grads, ws, S(t), ws + c0.a, nullptr, ws + n->x4, st));
+            OSI_TRY(bn_conv_wgrad(n, 0, params, grads, ws, t, ws + c0.a, nullptr, ws + n->x4, st));
             n->give(t);
             n->cur_grad = -1;
             n->fwd_done = false;
         }
+        // every gradient of this stage's slice of the arena is final on `st` from here on (the DP layer reduces it next)
+        OSI_TRY(n->join_side(st));
         n->next_stage = stage + 1;
     }
+    return OSI_OK;
+}
+
+int osi_resnet50_set_overlap(osi_resnet50_t n, int enable) {
+    OSI_REQUIRE(n);
+    n->overlap = enable != 0;
     return OSI_OK;
 }
 

@@ -72,6 +72,7 @@ _SIGS = {
     "osi_resnet50_workspace_bytes": (c_size_t, [c_void_p]),
     "osi_resnet50_num_stages": (c_int, [c_void_p]),
     "osi_resnet50_stage_grad_range": (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    "osi_resnet50_set_overlap": (c_int, [c_void_p, c_int]),
     "osi_resnet50_profile": (c_int, [c_void_p, c_int]),
     "osi_resnet50_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int)]),
     "osi_resnet50_forward": (c_int, [c_void_p, P, P, P, P, P, P, P, c_int, P]),

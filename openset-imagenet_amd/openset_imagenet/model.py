@@ -16,6 +16,7 @@ There is no CPU path: calling the module with a CPU tensor raises.
 """
 import ctypes
 import math
+import os
 import weakref
 
 import torch
@@ -38,6 +39,8 @@ class _Net:
         self.h = ctypes.c_void_p()
         N.check(N.lib().osi_resnet50_create(ctypes.byref(self.h), B, H, W, F, O, int(bool(logit_bias))), "osi_resnet50_create")
         self.ws_bytes = N.lib().osi_resnet50_workspace_bytes(self.h)
+        if os.environ.get("OSI_NO_OVERLAP"):  # A/B switch: keep the weight-gradient kernels on the main stream
+            N.check(N.lib().osi_resnet50_set_overlap(self.h, 0))
 
     def __del__(self):
         try:
