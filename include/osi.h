@@ -42,7 +42,8 @@ typedef struct {
     int R, S, stride, pad;
 } osi_conv_desc;
 
-enum { OSI_TILE_AUTO = 0, OSI_TILE_128x128 = 1, OSI_TILE_128x64 = 2, OSI_TILE_64x128 = 3, OSI_TILE_64x64 = 4 };
+enum { OSI_TILE_AUTO = 0, OSI_TILE_128x128 = 1, OSI_TILE_128x64 = 2, OSI_TILE_64x128 = 3, OSI_TILE_64x64 = 4,
+       OSI_TILE_64x64_S1 = 5, OSI_TILE_64x128_S1 = 6, OSI_TILE_128x128_S1 = 7, OSI_TILE_128x64_S1 = 8 /* _S1: single-buffered LDS */ };
 
 /* y = conv2d(x, w), bias-free. The 7x7 stem is described with Cin = 4 (image staged by osi_nchw3_to_nhwc4) and takes
  * weights packed by osi_stem_weight_pack ([Cout][56 taps][4]). Otherwise Cin % 32 == 0, Cout % 64 == 0. */

@@ -23,6 +23,7 @@
 // The K order inside a stage is permuted identically for both operands (lane half h of MFMA (j,e) consumes
 // k = 8j + 4h + e), which a dot product does not care about.
 #include "osi_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -128,8 +129,10 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // ======================================================================================================
 // Forward
 // ======================================================================================================
-template <int WM, int WN, bool STEM>
-__global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {
+// NST = LDS stages: 2 = double buffered (one barrier per K tile), 1 = single buffered (two barriers, half the LDS, twice the
+// resident workgroups per CU)
+template <int WM, int WN, bool STEM, int NST>
+__global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_conv_fwd(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32, BR = BN / 32;  // float4 loads per thread per stage
     constexpr int STAGE = (BM + BN) * LDR;
@@ -212,11 +215,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {
     sstore(0);
     __syncthreads();
     for (int t = 0; t < T; ++t) {
-        const int buf = t & 1;
+        const int buf = NST == 2 ? (t & 1) : 0;
         if (t + 1 < T) { gload(t + 1); advance(); }
         const float* sA = smem + buf * STAGE;
         mma_RR<WM, WN>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
-        if (t + 1 < T) sstore(buf ^ 1);
+        if (NST == 1) __syncthreads();  // every wave is done reading the only stage
+        if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -242,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {
 // class only visits the filter taps that can reach it, so no MFMA work is spent on structural zeros.
 // blockIdx.y = class. GEMM N = Cin, K = (taps of the class) x Cout.
 // ======================================================================================================
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0) {
+template <int WM, int WN, int NST>
+__global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32;
     constexpr int LDC = BN + 4;
@@ -341,11 +345,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0
         sstore(0);
         __syncthreads();
         for (int t = 0; t < T; ++t) {
-            const int buf = t & 1;
+            const int buf = NST == 2 ? (t & 1) : 0;
             if (t + 1 < T) { gload(); advance(); }
             const float* sA = smem + buf * STAGE;
             mma_RC<WM, WN, LDC>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
-            if (t + 1 < T) sstore(buf ^ 1);
+            if (NST == 1) __syncthreads();
+            if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
             __syncthreads();
         }
     }
@@ -390,8 +395,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0
 // Weight gradient. GEMM rows = cout, cols = (tap, cin range), K = pixels. blockIdx.y = K split.
 // STEM: Cin = 4 (padded RGB), 56 padded taps -> 224 columns, a column tile spans 16 taps.
 // ======================================================================================================
-template <int WM, int WN, bool STEM>
-__global__ __launch_bounds__(256, 2) void k_conv_wgrad(ConvP p) {
+template <int WM, int WN, bool STEM, int NST>
+__global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int AV = BM / 4, ARP = 256 / AV, ARN = BK / ARP;
@@ -472,11 +477,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(ConvP p) {
         sstore(0);
         __syncthreads();
         for (int t = 0; t < T; ++t) {
-            const int buf = t & 1;
+            const int buf = NST == 2 ? (t & 1) : 0;
             if (t + 1 < T) gload(t + 1);
             const float* sA = smem + buf * STAGE;
             mma_CC<WM, WN, LDA, LDB>(sA, sA + BK * LDA, wm * 32 * WM, wn * 32 * WN, lane, acc);
-            if (t + 1 < T) sstore(buf ^ 1);
+            if (NST == 1) __syncthreads();
+            if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
             __syncthreads();
         }
     }
@@ -571,18 +577,18 @@ static ConvP make_p(const osi_conv_desc* d) {
     return p;
 }
 
-template <int WM, int WN, bool STEM>
+template <int WM, int WN, bool STEM, int NST = 2>
 static int launch_fwd(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     p.MT = osi_cdiv(p.M, BM); p.NT = p.Cout / BN;
-    size_t smem = 2 * (size_t)(BM + BN) * LDR * sizeof(float);
-    if (int e = set_smem(k_conv_fwd<WM, WN, STEM>, smem)) return e;
+    size_t smem = NST * (size_t)(BM + BN) * LDR * sizeof(float);
+    if (int e = set_smem(k_conv_fwd<WM, WN, STEM, NST>, smem)) return e;
     int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
-    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM, NST>), dim3(grid), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
-template <int WM, int WN>
+template <int WM, int WN, int NST = 2>
 static int launch_dgrad(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int s = p.stride;
@@ -596,20 +602,22 @@ static int launch_dgrad(ConvP p, hipStream_t st) {
     const int Hc = osi_cdiv(p.H, s), Wc = osi_cdiv(p.W, s);  // largest class
     p.MT = osi_cdiv((long)p.B * Hc * Wc, BM); p.NT = p.Cin / BN;
     size_t smem = 2 * (size_t)(BM * LDR + BK * (BN + 4)) * sizeof(float);
-    if (int e = set_smem(k_conv_dgrad<WM, WN>, smem)) return e;
+    smem = smem / 2 * NST;
+    if (int e = set_smem(k_conv_dgrad<WM, WN, NST>, smem)) return e;
     int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
-    hipLaunchKernelGGL((k_conv_dgrad<WM, WN>), dim3(grid, s * s), dim3(256), smem, st, p, Hc, Wc);
+    hipLaunchKernelGGL((k_conv_dgrad<WM, WN, NST>), dim3(grid, s * s), dim3(256), smem, st, p, Hc, Wc);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
-template <int WM, int WN, bool STEM>
+template <int WM, int WN, bool STEM, int NST = 2>
 static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     p.MT = p.Cout / BM;
     p.NT = STEM ? osi_cdiv(p.Ktot, BN) : p.R * p.S * (p.Cin / BN);
     size_t smem = 2 * (size_t)BK * (BM + 4 + BN + 4) * sizeof(float);
-    if (int e = set_smem(k_conv_wgrad<WM, WN, STEM>, smem)) return e;
-    hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM>), dim3(p.MT * p.NT, splits), dim3(256), smem, st, p);
+    smem = smem / 2 * NST;
+    if (int e = set_smem(k_conv_wgrad<WM, WN, STEM, NST>, smem)) return e;
+    hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST>), dim3(p.MT * p.NT, splits), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
@@ -619,8 +627,9 @@ struct WgradPlan { int wm, wn, splits, kchunk; };
 static WgradPlan plan_wgrad(const osi_conv_desc* d) {
     WgradPlan w;
     const bool stem = is_stem(d);
-    w.wm = (d->Cout % 128 == 0) ? 2 : 1;
-    w.wn = (!stem && d->Cin % 128 == 0) ? 2 : 1;
+    static const int force64 = getenv("OSI_WGRAD_TILE") ? atoi(getenv("OSI_WGRAD_TILE")) == 64 : 0;
+    w.wm = (!force64 && d->Cout % 128 == 0) ? 2 : 1;
+    w.wn = (!force64 && !stem && d->Cin % 128 == 0) ? 2 : 1;
     const int BMg = 64 * w.wm, BNg = 64 * w.wn;
     const int Ktot = stem ? 224 : d->R * d->S * d->Cin;
     const long tiles = (long)(d->Cout / BMg) * (stem ? osi_cdiv(Ktot, BNg) : d->R * d->S * (d->Cin / BNg));
@@ -653,14 +662,19 @@ int osi_conv_fwd(const osi_conv_desc* d, const float* x, const float* w, float* 
         // Measured on MI355X over the 22 ResNet-50 shapes at B=128 (tools/bench_conv.py, profiles/conv_layers_r01.txt): many
         // small workgroups (4 resident per CU) beat large tiles almost everywhere because the ragged last round of the launch is
         // shorter; only the 7x7-spatial layers with few column tiles prefer the wider 64x128 tile.
-        const long tiles64 = ((long)p.M + 63) / 64 * (d->Cout / 64);
-        tile = (tiles64 < 1024 && d->Cout % 128 == 0) ? OSI_TILE_64x128 : OSI_TILE_64x64;
+        // Single-buffered LDS (two barriers per K tile, but 7-8 resident workgroups per CU) beats the double-buffered form on
+        // every shape: occupancy, not staging depth, is what hides the barrier and load latency of a 16-MFMA K step.
+        tile = d->Cout >= 512 ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
     }
     switch (tile) {
         case OSI_TILE_128x128: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<2, 2, false>(p, st);
         case OSI_TILE_128x64: return launch_fwd<2, 1, false>(p, st);
         case OSI_TILE_64x128: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<1, 2, false>(p, st);
         case OSI_TILE_64x64: return launch_fwd<1, 1, false>(p, st);
+        case OSI_TILE_64x64_S1: return launch_fwd<1, 1, false, 1>(p, st);
+        case OSI_TILE_64x128_S1: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<1, 2, false, 1>(p, st);
+        case OSI_TILE_128x128_S1: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<2, 2, false, 1>(p, st);
+        case OSI_TILE_128x64_S1: return launch_fwd<2, 1, false, 1>(p, st);
         default: return OSI_ERR_ARG;
     }
 }
@@ -674,14 +688,24 @@ int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, floa
     ConvP p = make_p(d);
     p.x = dy; p.w = w; p.y = dx; p.accumulate = accumulate;
     if (tile == OSI_TILE_AUTO)  // measured (see osi_conv_fwd): 64 rows x the widest column tile the input channels allow
-        tile = d->Cin % 128 == 0 ? OSI_TILE_64x128 : OSI_TILE_64x64;
+        tile = d->Cin % 128 == 0 ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
     switch (tile) {
         case OSI_TILE_128x128: OSI_REQUIRE(d->Cin % 128 == 0); return launch_dgrad<2, 2>(p, st);
         case OSI_TILE_128x64: return launch_dgrad<2, 1>(p, st);
         case OSI_TILE_64x128: OSI_REQUIRE(d->Cin % 128 == 0); return launch_dgrad<1, 2>(p, st);
         case OSI_TILE_64x64: return launch_dgrad<1, 1>(p, st);
+        case OSI_TILE_64x64_S1: return launch_dgrad<1, 1, 1>(p, st);
+        case OSI_TILE_64x128_S1: OSI_REQUIRE(d->Cin % 128 == 0); return launch_dgrad<1, 2, 1>(p, st);
+        case OSI_TILE_128x128_S1: OSI_REQUIRE(d->Cin % 128 == 0); return launch_dgrad<2, 2, 1>(p, st);
+        case OSI_TILE_128x64_S1: return launch_dgrad<2, 1, 1>(p, st);
         default: return OSI_ERR_ARG;
     }
+}
+
+// Development switches (environment, read once): OSI_WGRAD_NST=1|2 LDS stages, OSI_WGRAD_TILE=64 forces 64x64 tiles.
+static int wgrad_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 size_t osi_conv_wgrad_workspace(const osi_conv_desc* d) {
@@ -705,11 +729,12 @@ int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, floa
     p.x = x; p.w = dy; p.y = w.splits > 1 ? (float*)ws : dw;
     p.kchunk = w.kchunk; p.slab_stride = n;
     int e;
+    static const int nst = wgrad_env("OSI_WGRAD_NST", 1);
     if (stem) e = launch_wgrad<1, 1, true>(p, w.splits, st);
-    else if (w.wm == 2 && w.wn == 2) e = launch_wgrad<2, 2, false>(p, w.splits, st);
-    else if (w.wm == 2) e = launch_wgrad<2, 1, false>(p, w.splits, st);
-    else if (w.wn == 2) e = launch_wgrad<1, 2, false>(p, w.splits, st);
-    else e = launch_wgrad<1, 1, false>(p, w.splits, st);
+    else if (w.wm == 2 && w.wn == 2) e = nst == 1 ? launch_wgrad<2, 2, false, 1>(p, w.splits, st) : launch_wgrad<2, 2, false>(p, w.splits, st);
+    else if (w.wm == 2) e = nst == 1 ? launch_wgrad<2, 1, false, 1>(p, w.splits, st) : launch_wgrad<2, 1, false>(p, w.splits, st);
+    else if (w.wn == 2) e = nst == 1 ? launch_wgrad<1, 2, false, 1>(p, w.splits, st) : launch_wgrad<1, 2, false>(p, w.splits, st);
+    else e = nst == 1 ? launch_wgrad<1, 1, false, 1>(p, w.splits, st) : launch_wgrad<1, 1, false>(p, w.splits, st);
     if (e) return e;
     if (w.splits > 1) {
         size_t n4 = n / 4;

@@ -1,0 +1,133 @@
+"""CPU: the oracle (oracle/*.py) against vectors produced by the reference's own files (tests/golden/losses_reference.npz,
+written by tests/golden/make_golden.py from /root/reference/openset_imagenet/{losses,metrics,dataset}.py) and against the
+structural anchors of the reference model (parameter counts, state_dict keys)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses_oracle as L
+from oracle import resnet50_oracle as R
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "losses_reference.npz"))
+
+
+def _grad(fn, z):
+    z = z.clone().requires_grad_(True)
+    j = fn(z)
+    j.backward()
+    return j.detach(), z.grad
+
+
+def test_entropic_loss_matches_reference(G):
+    for name in G["eos.names"]:
+        p = f"eos.{name}."
+        z, y, w = torch.from_numpy(G[p + "logits"]), torch.from_numpy(G[p + "target"]), float(G[p + "w"])
+        j, g = _grad(lambda t: L.entropic_openset_loss(t, y, w), z)
+        assert abs(float(j) - float(G[p + "loss"])) <= 2e-6 * max(1, abs(float(G[p + "loss"]))), p
+        assert np.allclose(g.numpy(), G[p + "dlogits"], atol=3e-7), p
+        # closed form of SURVEY.md Appendix B.1: grad = (s_i p - t_i) / B
+        t = L.entropic_targets(y, z.shape[1], w, torch.float64)
+        closed = (t.sum(1, keepdim=True) * torch.softmax(z.double(), 1) - t) / z.shape[0]
+        assert np.allclose(closed.numpy(), G[p + "dlogits"], atol=3e-7), p
+
+
+def test_softmax_loss_matches_reference(G):
+    for name in G["sm.names"]:
+        p = f"sm.{name}."
+        z, y = torch.from_numpy(G[p + "logits"]), torch.from_numpy(G[p + "target"])
+        ref = float(G[p + "loss"])
+        if np.isnan(ref):
+            assert torch.isnan(L.softmax_loss(z, y)), "all-ignored batch -> NaN (torch semantics, kept)"
+            continue
+        j, g = _grad(lambda t: L.softmax_loss(t, y), z)
+        assert abs(float(j) - ref) <= 2e-6 * max(1, abs(ref)), p
+        assert np.allclose(g.numpy(), G[p + "dlogits"], atol=3e-7), p
+
+
+def test_garbage_loss_and_class_weights_match_reference(G):
+    for name in G["gb.names"]:
+        p = f"gb.{name}."
+        z, y = torch.from_numpy(G[p + "logits"]), torch.from_numpy(G[p + "target"])
+        cw = L.class_weights(torch.from_numpy(G[p + "csv_labels"]))
+        assert np.allclose(cw.numpy(), G[p + "class_weights"], rtol=1e-6), p
+        j, g = _grad(lambda t: L.garbage_loss(t, y, cw), z)
+        assert abs(float(j) - float(G[p + "loss"])) <= 2e-6 * max(1, abs(float(G[p + "loss"]))), p
+        assert np.allclose(g.numpy(), G[p + "dlogits"], atol=3e-7), p
+    # worked example of SURVEY.md Appendix B.5
+    labels = torch.tensor([-1] * 3 + [0] * 4 + [1] * 5 + [2] * 6)
+    assert np.allclose(L.class_weights(labels).numpy(), G["cw.example"])
+    assert np.allclose(G["cw.example"], [1.125, 0.9, 0.75, 1.5])
+
+
+def test_confidence_matches_reference(G):
+    for name in G["conf.names"]:
+        p = f"conf.{name}."
+        off, unk, last = G[p + "args"]
+        r = L.confidence(torch.from_numpy(G[p + "scores"]), torch.from_numpy(G[p + "target"]), float(off), int(unk),
+                         None if last == -999 else int(last))
+        assert np.allclose(np.array(r, dtype=np.float64), G[p + "result"], rtol=1e-6, atol=1e-7), p
+
+
+def test_objectosphere_definition():
+    """Build-defined term (parity unpinned): check the stated formula and its gradient on a hand-computable case."""
+    z = torch.zeros(2, 4)
+    y = torch.tensor([1, -1])
+    f = torch.tensor([[3.0, 4.0, 0, 0], [0.0, 0.0, 2.0, 0]], requires_grad=True)
+    j = L.objectosphere_loss(z, y, f, 1.0, xi=10.0, alpha=0.5)
+    eos = float(L.entropic_openset_loss(z, y, 1.0))
+    assert abs(float(j) - (eos + 0.5 * ((10 - 5) ** 2 + 2 ** 2) / 2)) < 1e-6
+    j.backward()
+    assert torch.allclose(f.grad[0], torch.tensor([-0.5 * 2 * 5 * 0.6 / 2, -0.5 * 2 * 5 * 0.8 / 2, 0, 0]))
+    assert torch.allclose(f.grad[1], torch.tensor([0, 0, 0.5 * 2 * 2 / 2, 0.0]))
+
+
+def test_model_structure_anchors():
+    convs = R.conv_inventory()
+    assert len(convs) == 53 and len({(c[1], c[2], c[3], c[4]) for c in convs}) <= 23
+    conv_params = sum(cin * cout * k * k for _, cin, cout, k, _, _ in convs)
+    bn_affine = sum(2 * cout for _, _, cout, *_ in convs)
+    assert conv_params == 23454912 and bn_affine == 53120
+    for C, total in ((30, 23570402), (116, 23759172), (152, 23842584), (1000, 26557032)):
+        assert conv_params + bn_affine + 2048 * C + C + C * C == total
+    keys = R.state_keys()
+    assert len(keys) == 321 and keys[0] == "resnet_base.conv1.weight" and keys[-1] == "logits.weight"
+    sd = R.init_state(10, 10)
+    assert list(sd) == keys and len(R.param_keys(sd)) == 162
+    macs = 0
+    h = 224
+    for name, cin, cout, k, s, pad in convs:
+        hin = 224 if name.endswith("base.conv1") else None
+    # MAC count at 224x224 = 4 087 136 256
+    hw = {"stem": 224}
+    x = 224
+    total = 0
+    x = (x + 6 - 7) // 2 + 1; total += x * x * 64 * 3 * 49
+    x = (x + 2 - 3) // 2 + 1
+    inpl = 64
+    for planes, blocks, stride in R.STAGES:
+        for b in range(blocks):
+            st = stride if b == 0 else 1
+            total += x * x * inpl * planes
+            xo = (x + 2 - 3) // st + 1
+            total += xo * xo * planes * planes * 9 + xo * xo * planes * planes * 4
+            if b == 0:
+                total += xo * xo * inpl * planes * 4
+            x, inpl = xo, planes * 4
+    assert total == 4087136256
+
+
+def test_oracle_forward_reproduces_committed_vectors(golden_dir):
+    """The oracle at the committed seeds reproduces tests/golden/model_oracle.npz (guards against silent drift of the restatement)."""
+    V = np.load(os.path.join(golden_dir, "model_oracle.npz"))
+    tag, (B, HW, C, seed) = "b8_128_c30", V["b8_128_c30.meta"]
+    gen = torch.Generator().manual_seed(int(seed))
+    sd = R.init_state(int(C), int(C), False, generator=gen)
+    x = torch.rand(int(B), 3, int(HW), int(HW), generator=gen)
+    logits, feats = R.forward({k: v.clone() for k, v in sd.items()}, x, True)
+    assert np.allclose(logits.numpy(), V[f"{tag}.f32.logits"], atol=2e-5)
+    assert np.allclose(logits.numpy(), V[f"{tag}.f64.logits"], atol=1e-4)
