@@ -79,6 +79,15 @@ int osi_bn_backward(const float* dout, const float* act, const float* y, const f
                     const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
                     size_t ws_bytes, osi_stream_t stream);
 
+/* Bitmask forms: the forward writes one bit per element ((BN(+res)) > 0; osi_bn_relu_mask_bytes of storage) next to the ReLU
+ * output, and the backward takes that mask instead of re-reading the activation tensor in both of its passes. */
+size_t osi_bn_relu_mask_bytes(int M, int C);
+int osi_bn_apply_relu_mask(const float* y, const float* residual, const float* scale, const float* shift, float* out,
+                           void* relu_mask, int M, int C, osi_stream_t stream);
+int osi_bn_backward_relu_mask(const float* dout, const void* relu_mask, const float* y, const float* mean, const float* invstd,
+                              const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
+                              size_t ws_bytes, osi_stream_t stream);
+
 /* ---- pooling / layout (ResNet.maxpool, ResNet.avgpool, flatten; image batch of train.py:128) --- */
 int osi_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int B, int H, int W, osi_stream_t stream);
 /* idx: B*Ho*Wo*C bytes (argmax position 0..8 per element) */

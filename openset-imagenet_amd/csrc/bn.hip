@@ -130,24 +130,54 @@ __global__ void k_bn_eval_coeffs(const float* rm, const float* rv, const float* 
 }
 
 // ---- apply: out = [relu]( y*scale + shift [+ res] ) ---------------------------------------------------
-template <bool RES, bool RELU>
+// ReLU bitmask: bit (i & 63) of word [(i >> 6) * 4 + c] = (component c of float4 #i is > 0 after BN(+res)). One bit per
+// element (1/32 of the tensor) lets both BatchNorm-backward passes skip re-reading the activation just to rebuild the mask.
+typedef unsigned long long u64;
+template <bool RES, bool RELU, bool BITS>
 __global__ __launch_bounds__(NT) void k_bn_apply(const f32x4* __restrict__ y, const f32x4* __restrict__ res,
                                                 const f32x4* __restrict__ scale, const f32x4* __restrict__ shift,
-                                                f32x4* __restrict__ out, size_t n4, int c4n) {
+                                                f32x4* __restrict__ out, u64* __restrict__ bits, size_t n4, int c4n) {
     size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     const size_t step = (size_t)gridDim.x * NT;
     for (; i < n4; i += step) {
         int c4 = (int)(i % (size_t)c4n);
         f32x4 v = y[i] * scale[c4] + shift[c4];
         if (RES) v += res[i];
+        if (BITS) {
+            const u64 b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+            if ((threadIdx.x & 63) == 0) {  // lane 0 carries the smallest (64-aligned) index of the wave
+                u64* w = bits + (i >> 6) * 4;
+                w[0] = b0; w[1] = b1; w[2] = b2; w[3] = b3;
+            }
+        }
         if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         out[i] = v;
     }
 }
+__device__ __forceinline__ f32x4 mask_by_bits(f32x4 g, const u64* __restrict__ bits, size_t i) {
+    const u64* w = bits + (i >> 6) * 4;
+    const int b = (int)(i & 63);
+    g.x = (w[0] >> b) & 1 ? g.x : 0.f; g.y = (w[1] >> b) & 1 ? g.y : 0.f;
+    g.z = (w[2] >> b) & 1 ? g.z : 0.f; g.w = (w[3] >> b) & 1 ? g.w : 0.f;
+    return g;
+}
 
 // ---- backward ---------------------------------------------------------------------------------------
-// g = dA * (act > 0) (act == nullptr: g = dA);  partial sums of g and g*xhat per workgroup
-__global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float* __restrict__ dA, const float* __restrict__ act,
+// g = dA * mask; mask from the activation (MODE 1: act > 0), from the forward's bitmask (MODE 2) or none (MODE 0).
+// Partial sums of g and g*xhat per workgroup.
+template <int MODE>
+__device__ __forceinline__ f32x4 masked(f32x4 gv, const void* m, size_t i) {
+    if (MODE == 1) {
+        f32x4 a = reinterpret_cast<const f32x4*>(m)[i];
+        gv.x = a.x > 0.f ? gv.x : 0.f; gv.y = a.y > 0.f ? gv.y : 0.f;
+        gv.z = a.z > 0.f ? gv.z : 0.f; gv.w = a.w > 0.f ? gv.w : 0.f;
+    } else if (MODE == 2) {
+        gv = mask_by_bits(gv, reinterpret_cast<const u64*>(m), i);
+    }
+    return gv;
+}
+template <int MODE>
+__global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float* __restrict__ dA, const void* __restrict__ msk,
                                                       const float* __restrict__ y, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, int M, int C, int rows_per_blk,
                                                       float* __restrict__ pdb, float* __restrict__ pdg) {
@@ -163,23 +193,26 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float* __restrict__
     for (int g = 0; g < sp.G; ++g) {
         const int c4 = g * sp.CV + cv;
         const bool colok = active && c4 * 4 < C;
-        f32x4 sb = {0, 0, 0, 0}, sg = {0, 0, 0, 0};
+        f32x4 sb = {0, 0, 0, 0}, sg = {0, 0, 0, 0}, sb2 = {0, 0, 0, 0}, sg2 = {0, 0, 0, 0};
         if (colok) {
             const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4];
             const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c4];
-            const f32x4* pd = reinterpret_cast<const f32x4*>(dA) + c4;
-            const f32x4* pa = act ? reinterpret_cast<const f32x4*>(act) + c4 : nullptr;
-            const f32x4* py = reinterpret_cast<const f32x4*>(y) + c4;
-            for (int r = r0 + rl; r < r1; r += sp.RL) {
-                f32x4 gv = pd[(size_t)r * ld];
-                if (pa) {
-                    f32x4 a = pa[(size_t)r * ld];
-                    gv.x = a.x > 0.f ? gv.x : 0.f; gv.y = a.y > 0.f ? gv.y : 0.f;
-                    gv.z = a.z > 0.f ? gv.z : 0.f; gv.w = a.w > 0.f ? gv.w : 0.f;
-                }
-                f32x4 xh = (py[(size_t)r * ld] - mu) * is;
-                sb += gv; sg += gv * xh;
+            const f32x4* pd = reinterpret_cast<const f32x4*>(dA);
+            const f32x4* py = reinterpret_cast<const f32x4*>(y);
+            int r = r0 + rl;
+            for (; r + sp.RL < r1; r += 2 * sp.RL) {  // two independent rows in flight
+                const size_t i0 = (size_t)r * ld + c4, i1 = (size_t)(r + sp.RL) * ld + c4;
+                f32x4 g0 = pd[i0], g1 = pd[i1], y0 = py[i0], y1 = py[i1];
+                g0 = masked<MODE>(g0, msk, i0); g1 = masked<MODE>(g1, msk, i1);
+                sb += g0; sg += g0 * ((y0 - mu) * is);
+                sb2 += g1; sg2 += g1 * ((y1 - mu) * is);
             }
+            for (; r < r1; r += sp.RL) {
+                const size_t i0 = (size_t)r * ld + c4;
+                f32x4 g0 = masked<MODE>(pd[i0], msk, i0);
+                sb += g0; sg += g0 * ((py[i0] - mu) * is);
+            }
+            sb += sb2; sg += sg2;
         }
         red[0][tid] = sb; red[1][tid] = sg;
         __syncthreads();
@@ -211,8 +244,8 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_final(const float* __restrict__ p
 }
 
 // dy = gamma*invstd * ( g - c1 - xhat*c2 ) ; optionally also emits g (the masked upstream gradient) for the skip path
-template <bool MASK, bool EMITG>
-__global__ __launch_bounds__(NT) void k_bn_bwd_apply(const f32x4* dA /* may alias dy */, const f32x4* __restrict__ act,
+template <int MODE, bool EMITG>
+__global__ __launch_bounds__(NT) void k_bn_bwd_apply(const f32x4* dA /* may alias dy */, const void* __restrict__ msk,
                                                     const f32x4* __restrict__ y, const f32x4* __restrict__ mean,
                                                     const f32x4* __restrict__ invstd, const f32x4* __restrict__ gamma,
                                                     const f32x4* __restrict__ c1, const f32x4* __restrict__ c2,
@@ -221,12 +254,7 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const f32x4* dA /* may alia
     const size_t step = (size_t)gridDim.x * NT;
     for (; i < n4; i += step) {
         int c4 = (int)(i % (size_t)c4n);
-        f32x4 gv = dA[i];
-        if (MASK) {
-            f32x4 a = act[i];
-            gv.x = a.x > 0.f ? gv.x : 0.f; gv.y = a.y > 0.f ? gv.y : 0.f;
-            gv.z = a.z > 0.f ? gv.z : 0.f; gv.w = a.w > 0.f ? gv.w : 0.f;
-        }
+        f32x4 gv = masked<MODE>(dA[i], msk, i);
         f32x4 is = invstd[c4];
         f32x4 xh = (y[i] - mean[c4]) * is;
         f32x4 r = (gv - c1[c4] - xh * c2[c4]) * (gamma[c4] * is);
@@ -292,18 +320,71 @@ int osi_bn_eval_coeffs(const float* running_mean, const float* running_var, cons
     return OSI_OK;
 }
 
-int osi_bn_apply(const float* y, const float* residual, const float* scale, const float* shift, float* out, int M, int C,
-                 int relu, osi_stream_t stream) {
+static int bn_apply_impl(const float* y, const float* residual, const float* scale, const float* shift, float* out, void* bits,
+                         int M, int C, int relu, hipStream_t st) {
     OSI_REQUIRE(y && scale && shift && out && M > 0 && C > 0 && C % 4 == 0);
-    hipStream_t st = (hipStream_t)stream;
+    OSI_REQUIRE(!bits || relu);
     const size_t n4 = (size_t)M * C / 4;
     const int grid = stream_grid(n4), c4n = C / 4;
     auto Y = (const f32x4*)y; auto R = (const f32x4*)residual; auto S = (const f32x4*)scale; auto H = (const f32x4*)shift;
-    auto O = (f32x4*)out;
-    if (residual && relu) hipLaunchKernelGGL((k_bn_apply<true, true>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, n4, c4n);
-    else if (residual) hipLaunchKernelGGL((k_bn_apply<true, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, n4, c4n);
-    else if (relu) hipLaunchKernelGGL((k_bn_apply<false, true>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, n4, c4n);
-    else hipLaunchKernelGGL((k_bn_apply<false, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, n4, c4n);
+    auto O = (f32x4*)out; auto B = (u64*)bits;
+    if (bits && residual) hipLaunchKernelGGL((k_bn_apply<true, true, true>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
+    else if (bits) hipLaunchKernelGGL((k_bn_apply<false, true, true>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
+    else if (residual && relu) hipLaunchKernelGGL((k_bn_apply<true, true, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
+    else if (residual) hipLaunchKernelGGL((k_bn_apply<true, false, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
+    else if (relu) hipLaunchKernelGGL((k_bn_apply<false, true, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
+    else hipLaunchKernelGGL((k_bn_apply<false, false, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+int osi_bn_apply(const float* y, const float* residual, const float* scale, const float* shift, float* out, int M, int C,
+                 int relu, osi_stream_t stream) {
+    return bn_apply_impl(y, residual, scale, shift, out, nullptr, M, C, relu, (hipStream_t)stream);
+}
+
+size_t osi_bn_relu_mask_bytes(int M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    const size_t n4 = (size_t)M * C / 4;
+    return (n4 + 63) / 64 * 4 * sizeof(u64);
+}
+
+int osi_bn_apply_relu_mask(const float* y, const float* residual, const float* scale, const float* shift, float* out,
+                           void* relu_mask, int M, int C, osi_stream_t stream) {
+    OSI_REQUIRE(relu_mask);
+    return bn_apply_impl(y, residual, scale, shift, out, relu_mask, M, C, 1, (hipStream_t)stream);
+}
+
+static int bn_backward_impl(const float* dout, const void* msk, int mode, const float* y, const float* mean, const float* invstd,
+                            const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
+                            size_t ws_bytes, hipStream_t st) {
+    OSI_REQUIRE(dout && y && mean && invstd && gamma && dy && dgamma && dbeta && ws);
+    OSI_REQUIRE(M > 0 && C > 0 && C % 4 == 0);
+    int P;
+    int rpb = rows_per_block(M, C, P);
+    // partial sums + the two per-channel coefficient vectors
+    OSI_REQUIRE(ws_bytes >= ((size_t)2 * P * C + 2 * (size_t)C) * sizeof(float));
+    float* pdb = (float*)ws;
+    float* pdg = pdb + (size_t)P * C;
+    float* c1 = pdg + (size_t)P * C;
+    float* c2 = c1 + C;
+    if (mode == 2) hipLaunchKernelGGL(k_bn_bwd_partial<2>, dim3(P), dim3(NT), 0, st, dout, msk, y, mean, invstd, M, C, rpb, pdb, pdg);
+    else if (mode == 1) hipLaunchKernelGGL(k_bn_bwd_partial<1>, dim3(P), dim3(NT), 0, st, dout, msk, y, mean, invstd, M, C, rpb, pdb, pdg);
+    else hipLaunchKernelGGL(k_bn_bwd_partial<0>, dim3(P), dim3(NT), 0, st, dout, msk, y, mean, invstd, M, C, rpb, pdb, pdg);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, pdb, pdg, P, M, C, dgamma, dbeta, c1, c2);
+    OSI_LAUNCH_CHECK();
+    const size_t n4 = (size_t)M * C / 4;
+    const int grid = stream_grid(n4), c4n = C / 4;
+    auto D = (const f32x4*)dout; auto Y = (const f32x4*)y;
+    auto MU = (const f32x4*)mean; auto IS = (const f32x4*)invstd; auto G = (const f32x4*)gamma;
+    auto C1 = (const f32x4*)c1; auto C2 = (const f32x4*)c2;
+    auto DY = (f32x4*)dy; auto GO = (f32x4*)gmasked;
+#define OSI_BWD_APPLY(MODE_, EMIT_) hipLaunchKernelGGL((k_bn_bwd_apply<MODE_, EMIT_>), dim3(grid), dim3(NT), 0, st, D, msk, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n)
+    if (mode == 2) { if (gmasked) OSI_BWD_APPLY(2, true); else OSI_BWD_APPLY(2, false); }
+    else if (mode == 1) { if (gmasked) OSI_BWD_APPLY(1, true); else OSI_BWD_APPLY(1, false); }
+    else { if (gmasked) OSI_BWD_APPLY(0, true); else OSI_BWD_APPLY(0, false); }
+#undef OSI_BWD_APPLY
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
@@ -311,34 +392,16 @@ int osi_bn_apply(const float* y, const float* residual, const float* scale, cons
 int osi_bn_backward(const float* dout, const float* act, const float* y, const float* mean, const float* invstd,
                     const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
                     size_t ws_bytes, osi_stream_t stream) {
-    OSI_REQUIRE(dout && y && mean && invstd && gamma && dy && dgamma && dbeta && ws);
-    OSI_REQUIRE(M > 0 && C > 0 && C % 4 == 0);
-    OSI_REQUIRE(!(gmasked && !act) || true);
-    int P;
-    int rpb = rows_per_block(M, C, P);
-    // partial sums + the two per-channel coefficient vectors
-    OSI_REQUIRE(ws_bytes >= ((size_t)2 * P * C + 2 * (size_t)C) * sizeof(float));
-    hipStream_t st = (hipStream_t)stream;
-    float* pdb = (float*)ws;
-    float* pdg = pdb + (size_t)P * C;
-    float* c1 = pdg + (size_t)P * C;
-    float* c2 = c1 + C;
-    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(P), dim3(NT), 0, st, dout, act, y, mean, invstd, M, C, rpb, pdb, pdg);
-    OSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, pdb, pdg, P, M, C, dgamma, dbeta, c1, c2);
-    OSI_LAUNCH_CHECK();
-    const size_t n4 = (size_t)M * C / 4;
-    const int grid = stream_grid(n4), c4n = C / 4;
-    auto D = (const f32x4*)dout; auto A = (const f32x4*)act; auto Y = (const f32x4*)y;
-    auto MU = (const f32x4*)mean; auto IS = (const f32x4*)invstd; auto G = (const f32x4*)gamma;
-    auto C1 = (const f32x4*)c1; auto C2 = (const f32x4*)c2;
-    auto DY = (f32x4*)dy; auto GO = (f32x4*)gmasked;
-    if (act && gmasked) hipLaunchKernelGGL((k_bn_bwd_apply<true, true>), dim3(grid), dim3(NT), 0, st, D, A, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n);
-    else if (act) hipLaunchKernelGGL((k_bn_bwd_apply<true, false>), dim3(grid), dim3(NT), 0, st, D, A, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n);
-    else if (gmasked) hipLaunchKernelGGL((k_bn_bwd_apply<false, true>), dim3(grid), dim3(NT), 0, st, D, A, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n);
-    else hipLaunchKernelGGL((k_bn_bwd_apply<false, false>), dim3(grid), dim3(NT), 0, st, D, A, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n);
-    OSI_LAUNCH_CHECK();
-    return OSI_OK;
+    return bn_backward_impl(dout, act, act ? 1 : 0, y, mean, invstd, gamma, dy, gmasked, dgamma, dbeta, M, C, ws, ws_bytes,
+                            (hipStream_t)stream);
+}
+
+int osi_bn_backward_relu_mask(const float* dout, const void* relu_mask, const float* y, const float* mean, const float* invstd,
+                              const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
+                              size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(relu_mask);
+    return bn_backward_impl(dout, relu_mask, 2, y, mean, invstd, gamma, dy, gmasked, dgamma, dbeta, M, C, ws, ws_bytes,
+                            (hipStream_t)stream);
 }
 
 size_t osi_bn_backward_workspace(int M, int C) {

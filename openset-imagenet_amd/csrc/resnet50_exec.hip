@@ -40,6 +40,7 @@ struct Conv {
     int bn;
     size_t y;      // workspace: conv output (pre-BN)
     size_t a;      // workspace: BN(+res)+ReLU output (SIZE_MAX for downsample: goes to scratch)
+    size_t mask;   // workspace: ReLU bitmask of `a` (1 bit per element)
 };
 struct Block {
     int c1, c2, c3, ds;  // conv indices, ds = -1 if identity skip
@@ -123,6 +124,7 @@ struct osi_resnet50 {
         size_t n = (size_t)b.M * Cout;
         c.y = ws_alloc(n);
         c.a = keep_act ? ws_alloc(n) : (size_t)-1;
+        c.mask = keep_act ? ws_alloc(osi_bn_relu_mask_bytes(b.M, Cout) / sizeof(float)) : (size_t)-1;
         convs.push_back(c);
         return (int)convs.size() - 1;
     }
@@ -340,7 +342,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     n->mark(OSI_PROF_OTHER, st);
     OSI_TRY(conv_bn_fwd(n, 0, params, buffers, ws, ws + n->x4, ws + n->wpack, training, st));
     BN& b0 = n->bns[c0.bn];
-    OSI_TRY(osi_bn_apply(ws + c0.y, nullptr, ws + b0.scale, ws + b0.shift, ws + c0.a, b0.M, 64, 1, st));
+    OSI_TRY(osi_bn_apply_relu_mask(ws + c0.y, nullptr, ws + b0.scale, ws + b0.shift, ws + c0.a, ws + c0.mask, b0.M, 64, st));
     n->mark(OSI_PROF_BN_FWD, st);
     OSI_TRY(osi_maxpool3x3s2_fwd(ws + c0.a, ws + n->a_pool, ws + n->pool_idx, n->B, n->Hs, n->Ws, 64, st));
     n->mark(OSI_PROF_OTHER, st);
@@ -354,7 +356,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
             BN& b = n->bns[c.bn];
             OSI_TRY(conv_bn_fwd(n, cs[j], params, buffers, ws, in, params + c.w_off, training, st));
             if (j < 2) {
-                OSI_TRY(osi_bn_apply(ws + c.y, nullptr, ws + b.scale, ws + b.shift, ws + c.a, b.M, b.C, 1, st));
+                OSI_TRY(osi_bn_apply_relu_mask(ws + c.y, nullptr, ws + b.scale, ws + b.shift, ws + c.a, ws + c.mask, b.M, b.C, st));
                 n->mark(OSI_PROF_BN_FWD, st);
                 in = ws + c.a;
             }
@@ -371,7 +373,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
         }
         Conv& c3 = n->convs[k.c3];
         BN& b3 = n->bns[c3.bn];
-        OSI_TRY(osi_bn_apply(ws + c3.y, res, ws + b3.scale, ws + b3.shift, ws + c3.a, b3.M, b3.C, 1, st));
+        OSI_TRY(osi_bn_apply_relu_mask(ws + c3.y, res, ws + b3.scale, ws + b3.shift, ws + c3.a, ws + c3.mask, b3.M, b3.C, st));
         n->mark(OSI_PROF_BN_FWD, st);
     }
     // head
@@ -421,13 +423,13 @@ static int wgrad(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const
 }
 
 // backward of conv+BN(+ReLU mask): dout (in scratch buffer gi) -> dy in place, then wgrad; returns with dy still in the buffer
-static int bn_conv_wgrad(osi_resnet50* n, int ci, const float* params, float* grads, float* ws, int gi, const float* act,
+static int bn_conv_wgrad(osi_resnet50* n, int ci, const float* params, float* grads, float* ws, int gi,
                          float* gmasked, const float* conv_in, hipStream_t st) {
     Conv& c = n->convs[ci];
     BN& b = n->bns[c.bn];
     float* g = ws + n->scratch[gi];
-    OSI_TRY(osi_bn_backward(g, act, ws + c.y, ws + b.mean, ws + b.invstd, params + b.g_off, g, gmasked, grads + b.g_off,
-                            grads + b.b_off, b.M, b.C, ws + n->bn_ws, n->bn_ws_bytes, st));
+    OSI_TRY(osi_bn_backward_relu_mask(g, ws + c.mask, ws + c.y, ws + b.mean, ws + b.invstd, params + b.g_off, g, gmasked,
+                                      grads + b.g_off, grads + b.b_off, b.M, b.C, ws + n->bn_ws, n->bn_ws_bytes, st));
     n->mark(OSI_PROF_BN_BWD, st);
     return wgrad(n, ci, grads, ws, gi, conv_in, st);
 }
@@ -470,7 +472,6 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             if (k.stage != stage) continue;
             int go = n->cur_grad;
             const float* x = ws + k.x_in;
-            const float* out = ws + k.out;
             Conv &c1 = n->convs[k.c1], &c2 = n->convs[k.c2], &c3 = n->convs[k.c3];
             int dx = n->take(st);
             if (dx < 0) return OSI_ERR_STATE;
@@ -480,30 +481,31 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
                 int t1 = n->take(st);
                 if (t1 < 0) return OSI_ERR_STATE;
                 // downsample branch: g = dOut*(out>0) -> BN -> conv
-                OSI_TRY(osi_bn_backward(S(go), out, ws + cd.y, ws + bd.mean, ws + bd.invstd, params + bd.g_off, S(t1), nullptr,
-                                        grads + bd.g_off, grads + bd.b_off, bd.M, bd.C, ws + n->bn_ws, n->bn_ws_bytes, st));
+                OSI_TRY(osi_bn_backward_relu_mask(S(go), ws + c3.mask, ws + cd.y, ws + bd.mean, ws + bd.invstd, params + bd.g_off,
+                                                  S(t1), nullptr, grads + bd.g_off, grads + bd.b_off, bd.M, bd.C, ws + n->bn_ws,
+                                                  n->bn_ws_bytes, st));
                 n->mark(OSI_PROF_BN_BWD, st);
                 OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
                 OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dx), 0, OSI_TILE_AUTO, st));
                 n->mark(OSI_PROF_CONV_DGRAD, st);
                 n->give(t1);
-                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, go, out, nullptr, ws + c2.a, st));
+                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, go, nullptr, ws + c2.a, st));
             } else {
                 // identity skip: the masked gradient itself continues to the block input
-                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, go, out, S(dx), ws + c2.a, st));
+                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, go, S(dx), ws + c2.a, st));
             }
             int t2 = n->take(st);
             if (t2 < 0) return OSI_ERR_STATE;
             OSI_TRY(osi_conv_dgrad(&c3.d, S(go), params + c3.w_off, S(t2), 0, OSI_TILE_AUTO, st));
             n->mark(OSI_PROF_CONV_DGRAD, st);
             n->give(go);
-            OSI_TRY(bn_conv_wgrad(n, k.c2, params, grads, ws, t2, ws + c2.a, nullptr, ws + c1.a, st));
+            OSI_TRY(bn_conv_wgrad(n, k.c2, params, grads, ws, t2, nullptr, ws + c1.a, st));
             int t3 = n->take(st);
             if (t3 < 0) return OSI_ERR_STATE;
             OSI_TRY(osi_conv_dgrad(&c2.d, S(t2), params + c2.w_off, S(t3), 0, OSI_TILE_AUTO, st));
             n->mark(OSI_PROF_CONV_DGRAD, st);
             n->give(t2);
-            OSI_TRY(bn_conv_wgrad(n, k.c1, params, grads, ws, t3, ws + c1.a, nullptr, x, st));
+            OSI_TRY(bn_conv_wgrad(n, k.c1, params, grads, ws, t3, nullptr, x, st));
             OSI_TRY(osi_conv_dgrad(&c1.d, S(t3), params + c1.w_off, S(dx), 1, OSI_TILE_AUTO, st));
             n->mark(OSI_PROF_CONV_DGRAD, st);
             n->give(t3);
@@ -518,15 +520,16 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             OSI_TRY(osi_maxpool3x3s2_bwd(S(go), ws + n->pool_idx, S(t), n->B, n->Hs, n->Ws, 64, st));
             n->mark(OSI_PROF_OTHER, st);
             n->give(go);
-            OSI_TRY(bn_conv_wgrad(n, 0, params, grads, ws, t, ws + c0.a, nullptr, ws + n->x4, st));
+            OSI_TRY(bn_conv_wgrad(n, 0, params, grads, ws, t, nullptr, ws + n->x4, st));
             n->give(t);
             n->cur_grad = -1;
             n->fwd_done = false;
         }
-        // every gradient of this stage's slice of the arena is final on `st` from here on (the DP layer reduces it next)
-        OSI_TRY(n->join_side(st));
         n->next_stage = stage + 1;
     }
+    // Join once per call: every gradient of the stages just run is final on `st` from here on. A data-parallel caller issues
+    // one stage per call (and reduces that slice next); a single-GPU caller issues all stages in one call and pays one join.
+    OSI_TRY(n->join_side(st));
     return OSI_OK;
 }
 

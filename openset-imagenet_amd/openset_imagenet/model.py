@@ -248,13 +248,15 @@ class ResNet50(nn.Module):
         dfeatures = None if dfeatures is None else dfeatures.contiguous().float()
         st = N.stream_of(dlogits)
         sync = self._grad_sync
-        for s in range(self._n_stages):
+        if sync is None:  # single GPU: all stages in one call (one side-stream join at the end)
             N.check(lib.osi_resnet50_backward(net.h, N.ptr(self._flat_params), N.ptr(self._flat_grads), N.ptr(self._ws),
-                                              N.ptr(dlogits), N.ptr(dfeatures), s, s + 1, st), "osi_resnet50_backward")
-            if sync is not None:
+                                              N.ptr(dlogits), N.ptr(dfeatures), 0, self._n_stages, st), "osi_resnet50_backward")
+        else:             # data parallel: stage by stage, each finished slice of the gradient arena goes to the all-reduce
+            for s in range(self._n_stages):
+                N.check(lib.osi_resnet50_backward(net.h, N.ptr(self._flat_params), N.ptr(self._flat_grads), N.ptr(self._ws),
+                                                  N.ptr(dlogits), N.ptr(dfeatures), s, s + 1, st), "osi_resnet50_backward")
                 lo, hi = self._stage_ranges[s]
                 sync.bucket_ready(self._flat_grads, lo, hi)
-        if sync is not None:
             sync.finish()
         self.bind_gradients()
 

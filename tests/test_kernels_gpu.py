@@ -340,3 +340,49 @@ def test_adam_sgd_vs_torch(cuda, n):
                 N.check(N.lib().osi_sgd_step(N.ptr(pg), N.ptr(gg), N.ptr(s1), n, 1e-2, 0.9, int(i == 0), 1.0, T.S()))
         d = float((pg.cpu() - pt.detach()).abs().max())
         assert d <= 1e-6, f"{kind}: max param diff {d}"
+
+
+@pytest.mark.parametrize("B,C,H,res", [(3, 64, 14, False), (2, 256, 7, True), (5, 12, 6, True), (2, 2048, 3, False)])
+def test_batchnorm_relu_bitmask_forms(cuda, B, C, H, res):
+    """The bitmask forms (forward writes 1 bit/element, backward consumes it) give the same bits as the activation-mask forms."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(C * 3 + H)
+    M = B * H * H
+    y = (torch.randn(M, C, generator=g)).to(cuda)
+    resid = torch.randn(M, C, generator=g).to(cuda) if res else None
+    ga, be = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+    dout = torch.randn(M, C, generator=g).to(cuda)
+    mean, invstd, scale, shift = (torch.empty(C, device=cuda) for _ in range(4))
+    wsb = max(L.osi_bn_workspace(M, C), L.osi_bn_backward_workspace(M, C))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    N.check(L.osi_bn_train_stats(N.ptr(y), M, C, N.ptr(ga), N.ptr(be), 1e-5, 0.1, None, None, N.ptr(mean), N.ptr(invstd), N.ptr(scale),
+                                 N.ptr(shift), N.ptr(ws), wsb, T.S()))
+    out1, out2 = torch.empty_like(y), torch.empty_like(y)
+    mb = L.osi_bn_relu_mask_bytes(M, C)
+    assert mb == ((M * C // 4 + 63) // 64) * 32
+    mask = torch.zeros(mb, dtype=torch.uint8, device=cuda)
+    N.check(L.osi_bn_apply(N.ptr(y), N.ptr(resid), N.ptr(scale), N.ptr(shift), N.ptr(out1), M, C, 1, T.S()))
+    N.check(L.osi_bn_apply_relu_mask(N.ptr(y), N.ptr(resid), N.ptr(scale), N.ptr(shift), N.ptr(out2), N.ptr(mask), M, C, T.S()))
+    assert torch.equal(out1, out2)
+    # unpack the mask on the host and compare with out > 0
+    words = mask.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    n4 = M * C // 4
+    idx = np.arange(n4)
+    bits = np.stack([(words[idx >> 6, c] >> (idx & 63).astype(np.uint64)) & 1 for c in range(4)], axis=1).reshape(-1).astype(bool)
+    assert np.array_equal(bits, (out1.cpu().numpy().reshape(-1) > 0))
+    res_a, res_b = [], []
+    for which, store in ((0, res_a), (1, res_b)):
+        dy, gm = torch.empty_like(y), torch.empty_like(y)
+        dg, db = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+        if which == 0:
+            N.check(L.osi_bn_backward(N.ptr(dout), N.ptr(out1), N.ptr(y), N.ptr(mean), N.ptr(invstd), N.ptr(ga), N.ptr(dy), N.ptr(gm),
+                                      N.ptr(dg), N.ptr(db), M, C, N.ptr(ws), wsb, T.S()))
+        else:
+            N.check(L.osi_bn_backward_relu_mask(N.ptr(dout), N.ptr(mask), N.ptr(y), N.ptr(mean), N.ptr(invstd), N.ptr(ga), N.ptr(dy),
+                                                N.ptr(gm), N.ptr(dg), N.ptr(db), M, C, N.ptr(ws), wsb, T.S()))
+        torch.cuda.synchronize()
+        store += [dy, gm, dg, db]
+    for a, b in zip(res_a, res_b):
+        assert torch.equal(a, b)
