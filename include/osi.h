@@ -48,6 +48,11 @@ enum { OSI_TILE_AUTO = 0, OSI_TILE_128x128 = 1, OSI_TILE_128x64 = 2, OSI_TILE_64
 /* y = conv2d(x, w), bias-free. The 7x7 stem is described with Cin = 4 (image staged by osi_nchw3_to_nhwc4) and takes
  * weights packed by osi_stem_weight_pack ([Cout][56 taps][4]). Otherwise Cin % 32 == 0, Cout % 64 == 0. */
 int osi_conv_fwd(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, osi_stream_t stream);
+/* Same convolution, and the epilogue also emits per-row-tile BatchNorm partials (mean, M2 per channel, *P tiles of
+ * *rows_per_block rows) into pstats, to be finished by osi_bn_finalize_stats — the statistics never re-read y from HBM. */
+size_t osi_conv_fwd_bnstats_workspace(const osi_conv_desc* d);
+int osi_conv_fwd_bnstats(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, float* pstats,
+                         size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
 /* dx (+)= conv2d_input_grad(dy, w). accumulate != 0 adds into dx (skip-connection sum). Cout % 32 == 0, Cin % 64 == 0. */
 int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, int tile,
                    osi_stream_t stream);
@@ -66,6 +71,10 @@ size_t osi_bn_workspace(int M, int C);
 int osi_bn_train_stats(const float* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
                        void* ws, size_t ws_bytes, osi_stream_t stream);
+/* second half of osi_bn_train_stats for partials produced elsewhere (osi_conv_fwd_bnstats): pstats = [P][C] means then [P][C] M2 */
+int osi_bn_finalize_stats(float* pstats, size_t pstats_bytes, int P, int rows_per_block, int M, int C, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                          float* invstd, float* scale, float* shift, osi_stream_t stream);
 /* eval mode (validate(), train.py:142-196): scale/shift from the running statistics */
 int osi_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
                        int C, float* scale, float* shift, osi_stream_t stream);

@@ -14,6 +14,7 @@
 namespace {
 
 constexpr int NT = 256;
+constexpr int OSI_BN_GROUPS = 32;  // level-1 groups of the two-level statistics finalisation
 
 struct RowSplit { int CV, RL, G; };  // float4 columns per pass, row lanes, column groups
 __host__ __device__ inline RowSplit row_split(int C) {
@@ -77,13 +78,113 @@ __global__ __launch_bounds__(NT) void k_bn_stats_partial(const float* __restrict
 
 // One wave per channel: every lane Chan-merges its share of the P per-workgroup (n, mean, M2) triples in a fixed order,
 // then a fixed xor-shuffle tree merges the 64 lanes. Deterministic, single pass over the partials.
-__device__ __forceinline__ void chan_merge(float& na, float& ma, float& sa, float nb, float mb, float sb) {
-    if (nb == 0.f) return;
-    if (na == 0.f) { na = nb; ma = mb; sa = sb; return; }
-    const float n = na + nb, d = mb - ma;
-    ma += d * (nb / n);
-    sa += sb + d * d * (na * nb / n);
-    na = n;
+__device__ __forceinline__ void bn_finish(int c, float mean, float m2, int M, const float* gamma, const float* beta, float eps,
+                                          float momentum, float* running_mean, float* running_var, float* mean_out,
+                                          float* invstd_out, float* scale_out, float* shift_out) {
+    float var = m2 / (float)M;
+    float invstd = 1.0f / sqrtf(var + eps);
+    mean_out[c] = mean; invstd_out[c] = invstd;
+    float sc = invstd * gamma[c];
+    scale_out[c] = sc; shift_out[c] = beta[c] - mean * sc;
+    if (running_mean) {
+        float unb = M > 1 ? m2 / (float)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+}
+// Row-major partials [P][C] as written by the conv-forward epilogue (osi_conv_fwd_bnstats): one workgroup = 16 channels x 16
+// partial lanes; every lane Chan-merges partials lane, lane+16, ... in order, lane 0 then merges the 16 lane results in order.
+__global__ __launch_bounds__(NT) void k_bn_stats_final_rows(const float* __restrict__ pmean, const float* __restrict__ pm2, int P,
+                                                           int rows_per_blk, int M, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* running_mean, float* running_var, float* __restrict__ mean_out,
+                                                           float* __restrict__ invstd_out, float* __restrict__ scale_out,
+                                                           float* __restrict__ shift_out) {
+    // division-free weighted form of the Chan merge: mean = sum n_b mean_b / M ; M2 = sum [ M2_b + n_b (mean_b - mean)^2 ]
+    __shared__ float red[16][16];
+    __shared__ float smean[16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const bool ok = c < C;
+    const int last = P - 1;
+    const float nfull = (float)rows_per_blk, nlast = (float)(M - last * rows_per_blk);
+    float a0 = 0.f, a1 = 0.f;
+    if (ok) {
+        int b = pl;
+        for (; b + 16 < P; b += 32) {
+            a0 += (b == last ? nlast : nfull) * pmean[(size_t)b * C + c];
+            a1 += (b + 16 == last ? nlast : nfull) * pmean[(size_t)(b + 16) * C + c];
+        }
+        if (b < P) a0 += (b == last ? nlast : nfull) * pmean[(size_t)b * C + c];
+    }
+    red[pl][cl] = a0 + a1;
+    __syncthreads();
+    if (pl == 0) {
+        float s = 0.f;
+        for (int k = 0; k < 16; ++k) s += red[k][cl];
+        smean[cl] = s / (float)M;
+    }
+    __syncthreads();
+    const float mean = smean[cl];
+    a0 = 0.f; a1 = 0.f;
+    if (ok) {
+        int b = pl;
+        for (; b + 16 < P; b += 32) {
+            const float d0 = pmean[(size_t)b * C + c] - mean, d1 = pmean[(size_t)(b + 16) * C + c] - mean;
+            a0 += pm2[(size_t)b * C + c] + (b == last ? nlast : nfull) * d0 * d0;
+            a1 += pm2[(size_t)(b + 16) * C + c] + (b + 16 == last ? nlast : nfull) * d1 * d1;
+        }
+        if (b < P) { const float d0 = pmean[(size_t)b * C + c] - mean; a0 += pm2[(size_t)b * C + c] + (b == last ? nlast : nfull) * d0 * d0; }
+    }
+    __syncthreads();
+    red[pl][cl] = a0 + a1;
+    __syncthreads();
+    if (pl == 0 && ok) {
+        float m2 = 0.f;
+        for (int k = 0; k < 16; ++k) m2 += red[k][cl];
+        bn_finish(c, mean, m2, M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
+    }
+}
+// Level 1 of the two-level finalisation: group s (blockIdx.y) reduces row tiles [s*Pc, (s+1)*Pc) of 16 channels to one
+// (mean, M2) pair per channel, division-free, written channel-major [C][S] for k_bn_stats_final.
+__global__ __launch_bounds__(NT) void k_bn_stats_group(const float* __restrict__ pmean, const float* __restrict__ pm2, int P, int Pc,
+                                                      int rows_per_blk, int M, int C, int S, float* __restrict__ gmean,
+                                                      float* __restrict__ gm2) {
+    __shared__ float red[16][16];
+    __shared__ float smean[16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl, s = blockIdx.y;
+    const bool ok = c < C;
+    const int b0 = s * Pc, b1 = min(P, b0 + Pc), last = P - 1;
+    const float nfull = (float)rows_per_blk, nlast = (float)(M - last * rows_per_blk);
+    const float ng = (float)(min(M, b1 * rows_per_blk) - b0 * rows_per_blk);
+    float a = 0.f;
+    if (ok)
+        for (int b = b0 + pl; b < b1; b += 16) a += (b == last ? nlast : nfull) * pmean[(size_t)b * C + c];
+    red[pl][cl] = a;
+    __syncthreads();
+    if (pl == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        smean[cl] = t / ng;
+    }
+    __syncthreads();
+    const float mean = smean[cl];
+    a = 0.f;
+    if (ok)
+        for (int b = b0 + pl; b < b1; b += 16) {
+            const float d = pmean[(size_t)b * C + c] - mean;
+            a += pm2[(size_t)b * C + c] + (b == last ? nlast : nfull) * d * d;
+        }
+    __syncthreads();
+    red[pl][cl] = a;
+    __syncthreads();
+    if (pl == 0 && ok) {
+        float m2 = 0.f;
+        for (int k = 0; k < 16; ++k) m2 += red[k][cl];
+        gmean[(size_t)c * S + s] = mean;
+        gm2[(size_t)c * S + s] = m2;
+    }
 }
 __global__ __launch_bounds__(NT) void k_bn_stats_final(const float* __restrict__ pmean, const float* __restrict__ pm2, int P,
                                                       int rows_per_blk, int M, int C, const float* __restrict__ gamma,
@@ -106,18 +207,8 @@ __global__ __launch_bounds__(NT) void k_bn_stats_final(const float* __restrict__
         if (lane & o) { float na = nb, ma = mb, sa = sb; chan_merge(na, ma, sa, n, mean, m2); n = na; mean = ma; m2 = sa; }
         else chan_merge(n, mean, m2, nb, mb, sb);
     }
-    if (lane == 0) {
-        float var = m2 / (float)M;
-        float invstd = 1.0f / sqrtf(var + eps);
-        mean_out[c] = mean; invstd_out[c] = invstd;
-        float sc = invstd * gamma[c];
-        scale_out[c] = sc; shift_out[c] = beta[c] - mean * sc;
-        if (running_mean) {
-            float unb = M > 1 ? m2 / (float)(M - 1) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
-        }
-    }
+    if (lane == 0)
+        bn_finish(c, mean, m2, M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
 }
 
 // eval mode: scale/shift from running statistics
@@ -307,6 +398,37 @@ int osi_bn_train_stats(const float* y, int M, int C, const float* gamma, const f
     OSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_stats_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, pmean, pm2, P, rpb, M, C, gamma, beta, eps,
                        momentum, running_mean, running_var, mean, invstd, scale, shift);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+int osi_bn_finalize_stats(float* pstats, size_t pstats_bytes, int P, int rows_per_block, int M, int C, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                          float* invstd, float* scale, float* shift, osi_stream_t stream) {
+    OSI_REQUIRE(pstats && gamma && beta && mean && invstd && scale && shift);
+    OSI_REQUIRE(P > 0 && rows_per_block > 0 && M > 0 && C > 0 && (long)(P - 1) * rows_per_block < M && (long)P * rows_per_block >= M);
+    OSI_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    OSI_REQUIRE(pstats_bytes >= ((size_t)2 * P * C + 2 * (size_t)OSI_BN_GROUPS * C) * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    const float* pmean = pstats;
+    const float* pm2 = pstats + (size_t)P * C;
+    if (P <= 32) {
+        hipLaunchKernelGGL(k_bn_stats_final_rows, dim3(osi_cdiv(C, 16)), dim3(NT), 0, st, pmean, pm2, P, rows_per_block, M, C, gamma,
+                           beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+        OSI_LAUNCH_CHECK();
+        return OSI_OK;
+    }
+    // two levels: S groups of Pc consecutive row tiles are reduced by S x C/16 workgroups, then one wave per channel merges them
+    int S = osi_cdiv(P, 64);
+    if (S > OSI_BN_GROUPS) S = OSI_BN_GROUPS;
+    const int Pc = osi_cdiv(P, S);
+    S = osi_cdiv(P, Pc);
+    float* gmean = pstats + (size_t)2 * P * C;
+    float* gm2 = gmean + (size_t)S * C;
+    hipLaunchKernelGGL(k_bn_stats_group, dim3(osi_cdiv(C, 16), S), dim3(NT), 0, st, pmean, pm2, P, Pc, rows_per_block, M, C, S, gmean, gm2);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_stats_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, (const float*)gmean, (const float*)gm2, S,
+                       Pc * rows_per_block, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }

@@ -42,6 +42,8 @@ struct ConvP {
     FastDiv dHoWo, dWo;  // fwd/wgrad: divide by Ho*Wo, Wo
     FastDiv cHW[4], cW[4];  // dgrad: Hc*Wc and Wc of each parity class grid (stride <= 2)
     int unit;             // dgrad: 1x1 stride-1 conv -> the im2col row of pixel m is row m of dY
+    float* pmean;         // fwd: optional BatchNorm partials [MT][Cout] (mean, M2) written by the epilogue
+    float* pm2;
     // wgrad only
     int kchunk;       // pixels per split
     size_t slab_stride;
@@ -239,6 +241,47 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
                 }
             }
         }
+
+    // Optional BatchNorm batch statistics of this workgroup's rows, straight from the accumulators (saves a full re-read of
+    // the conv output): per column a (count, mean, M2) triple per 32x32 tile -> Chan-merged over the wave's tiles -> over the
+    // two wave rows through LDS -> one (mean, M2) pair per column in pmean/pm2[mt][Cout]. Fixed order, no atomics.
+    if (p.pmean) {
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            float cn = 0.f, cm = 0.f, cs = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int row0 = m0 + wm * 32 * WM + i * 32;
+                const float cnt = (float)min(32, max(0, p.M - row0));
+                float s = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) s += (row0 + acc_row(rr, lane) < p.M) ? acc[i][n][rr] : 0.f;
+                s += __shfl_xor(s, 32, 64);
+                const float mu = cnt > 0.f ? s / cnt : 0.f;
+                float q = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const float dlt = acc[i][n][rr] - mu;
+                    q += (row0 + acc_row(rr, lane) < p.M) ? dlt * dlt : 0.f;
+                }
+                q += __shfl_xor(q, 32, 64);
+                chan_merge(cn, cm, cs, cnt, mu, q);
+            }
+            if (lane < 32) {
+                float* dst = smem + (wm * BN + wn * 32 * WN + n * 32 + lane) * 3;  // the K loop ended with a barrier: LDS is free
+                dst[0] = cn; dst[1] = cm; dst[2] = cs;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const float* a = smem + tid * 3;
+            const float* b = smem + (BN + tid) * 3;
+            float cn = a[0], cm = a[1], cs = a[2];
+            chan_merge(cn, cm, cs, b[0], b[1], b[2]);
+            p.pmean[(size_t)mt * p.Cout + n0 + tid] = cm;
+            p.pm2[(size_t)mt * p.Cout + n0 + tid] = cs;
+        }
+    }
 }
 
 // ======================================================================================================
@@ -648,13 +691,45 @@ static WgradPlan plan_wgrad(const osi_conv_desc* d) {
 
 extern "C" {
 
+static int fwd_tile_rows(int tile) {
+    return (tile == OSI_TILE_128x128 || tile == OSI_TILE_128x64 || tile == OSI_TILE_128x128_S1 || tile == OSI_TILE_128x64_S1) ? 128 : 64;
+}
+static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, float* pstats,
+                         size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
+
 int osi_conv_fwd(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, osi_stream_t stream) {
+    return conv_fwd_impl(d, x, w, y, tile, nullptr, 0, nullptr, nullptr, stream);
+}
+
+size_t osi_conv_fwd_bnstats_workspace(const osi_conv_desc* d) {
+    if (!desc_ok(d)) return 0;
+    // row-tile partials + the 32 group pairs of osi_bn_finalize_stats' first level
+    return ((size_t)2 * osi_cdiv((long)d->B * d->Ho * d->Wo, 64) * d->Cout + (size_t)2 * 32 * d->Cout) * sizeof(float);
+}
+
+int osi_conv_fwd_bnstats(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, float* pstats,
+                         size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream) {
+    OSI_REQUIRE(pstats && P && rows_per_block);
+    return conv_fwd_impl(d, x, w, y, tile, pstats, pstats_bytes, P, rows_per_block, stream);
+}
+
+static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, float* pstats,
+                         size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream) {
     OSI_REQUIRE(desc_ok(d) && x && w && y);
     hipStream_t st = (hipStream_t)stream;
     ConvP p = make_p(d);
     p.x = x; p.w = w; p.y = y; p.accumulate = 0;
+    auto with_stats = [&](int bm) -> int {
+        if (!pstats) return OSI_OK;
+        const int mt = osi_cdiv(p.M, bm);
+        if (pstats_bytes < (size_t)2 * mt * d->Cout * sizeof(float)) return OSI_ERR_ARG;
+        p.pmean = pstats; p.pm2 = pstats + (size_t)mt * d->Cout;
+        *P = mt; *rows_per_block = bm;
+        return OSI_OK;
+    };
     if (is_stem(d)) {
         OSI_REQUIRE(d->Cout % 64 == 0 && d->stride >= 1);
+        if (int e = with_stats(128)) return e;
         return launch_fwd<2, 1, true>(p, st);
     }
     OSI_REQUIRE(d->Cin % BK == 0 && d->Cout % 64 == 0);
@@ -666,6 +741,7 @@ int osi_conv_fwd(const osi_conv_desc* d, const float* x, const float* w, float* 
         // every shape: occupancy, not staging depth, is what hides the barrier and load latency of a 16-MFMA K step.
         tile = d->Cout >= 512 ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
     }
+    if (int e = with_stats(fwd_tile_rows(tile))) return e;
     switch (tile) {
         case OSI_TILE_128x128: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<2, 2, false>(p, st);
         case OSI_TILE_128x64: return launch_fwd<2, 1, false>(p, st);

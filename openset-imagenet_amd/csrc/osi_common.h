@@ -43,6 +43,16 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
     return (((n - t) >> 1) + t) >> (f.sh - 1);
 }
 
+// Chan/Welford merge of two (count, mean, M2) triples: a <- a (+) b. Exact in the counts, no E[x^2]-E[x]^2 cancellation.
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& sa, float nb, float mb, float sb) {
+    if (nb == 0.f) return;
+    if (na == 0.f) { na = nb; ma = mb; sa = sb; return; }
+    const float n = na + nb, d = mb - ma;
+    ma += d * (nb / n);
+    sa += sb + d * d * (na * nb / n);
+    na = n;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -242,6 +242,8 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
         size_t b1 = osi_bn_workspace(n->bns[c.bn].M, c.d.Cout), b2 = osi_bn_backward_workspace(n->bns[c.bn].M, c.d.Cout);
         if (b1 > bnws) bnws = b1;
         if (b2 > bnws) bnws = b2;
+        size_t b3 = osi_conv_fwd_bnstats_workspace(&c.d);
+        if (b3 > bnws) bnws = b3;
         size_t wg = osi_conv_wgrad_workspace(&c.d);
         if (wg > wgws) wgws = wg;
     }
@@ -314,15 +316,20 @@ static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buff
                        int training, hipStream_t st) {
     Conv& c = n->convs[ci];
     BN& b = n->bns[c.bn];
-    OSI_TRY(osi_conv_fwd(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, st));
-    n->mark(OSI_PROF_CONV_FWD, st);
-    if (training)
-        OSI_TRY(osi_bn_train_stats(ws + c.y, b.M, b.C, params + b.g_off, params + b.b_off, 1e-5f, 0.1f, buffers + b.rm_off,
-                                   buffers + b.rv_off, ws + b.mean, ws + b.invstd, ws + b.scale, ws + b.shift, ws + n->bn_ws,
-                                   n->bn_ws_bytes, st));
-    else
+    if (training) {
+        // batch statistics come out of the conv epilogue (per row tile), only a tiny per-channel merge follows
+        int P = 0, rows = 0;
+        OSI_TRY(osi_conv_fwd_bnstats(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, ws + n->bn_ws, n->bn_ws_bytes, &P, &rows, st));
+        n->mark(OSI_PROF_CONV_FWD, st);
+        OSI_TRY(osi_bn_finalize_stats(ws + n->bn_ws, n->bn_ws_bytes, P, rows, b.M, b.C, params + b.g_off, params + b.b_off, 1e-5f, 0.1f,
+                                      buffers + b.rm_off, buffers + b.rv_off, ws + b.mean, ws + b.invstd, ws + b.scale,
+                                      ws + b.shift, st));
+    } else {
+        OSI_TRY(osi_conv_fwd(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, st));
+        n->mark(OSI_PROF_CONV_FWD, st);
         OSI_TRY(osi_bn_eval_coeffs(buffers + b.rm_off, buffers + b.rv_off, params + b.g_off, params + b.b_off, 1e-5f, b.C,
                                    ws + b.scale, ws + b.shift, st));
+    }
     n->mark(OSI_PROF_BN_FWD, st);
     return OSI_OK;
 }

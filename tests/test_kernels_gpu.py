@@ -386,3 +386,39 @@ def test_batchnorm_relu_bitmask_forms(cuda, B, C, H, res):
         store += [dy, gm, dg, db]
     for a, b in zip(res_a, res_b):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,H,B", [(64, 64, 1, 1, 14, 3), (128, 128, 3, 2, 9, 3), (256, 512, 1, 1, 7, 5), (64, 256, 3, 1, 12, 2),
+                                                    (64, 64, 1, 1, 56, 3)])   # the last one has 147 row tiles -> two-level finalisation
+def test_conv_epilogue_batchnorm_statistics(cuda, Cin, Cout, k, stride, H, B):
+    """BN statistics emitted by the conv-forward epilogue + osi_bn_finalize_stats == statistics of the conv output (fp64),
+    for every tile shape (ragged last row tile included), and the conv output itself is unchanged."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    pad = 1 if k == 3 else 0
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=g) + 0.3
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    y64 = F.conv2d(x.double(), w.double(), None, stride, pad)
+    mean64 = y64.mean(dim=(0, 2, 3)); var64 = y64.var(dim=(0, 2, 3), unbiased=False)
+    xg, wg = T.nhwc(x).to(cuda), T.krsc(w).to(cuda)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, k, stride, pad)
+    M = B * d.Ho * d.Wo
+    ga, be = (torch.rand(Cout, generator=g) + 0.5).to(cuda), torch.randn(Cout, generator=g).to(cuda)
+    nb = L.osi_conv_fwd_bnstats_workspace(ctypes.byref(d))
+    for tile in [0, 4, 5, 2] + ([1, 3, 6] if Cout % 128 == 0 else []):
+        ps = torch.full((nb // 4,), float("nan"), device=cuda)
+        y = torch.empty(B, d.Ho, d.Wo, Cout, device=cuda)
+        P, rows = ctypes.c_int(), ctypes.c_int()
+        N.check(L.osi_conv_fwd_bnstats(ctypes.byref(d), N.ptr(xg), N.ptr(wg), N.ptr(y), tile, N.ptr(ps), nb, ctypes.byref(P), ctypes.byref(rows), T.S()))
+        assert torch.equal(y, T.conv_fwd(xg, wg, k, stride, pad, tile))
+        mean, invstd, scale, shift = (torch.empty(Cout, device=cuda) for _ in range(4))
+        rm, rv = torch.zeros(Cout, device=cuda), torch.ones(Cout, device=cuda)
+        N.check(L.osi_bn_finalize_stats(N.ptr(ps), nb, P.value, rows.value, M, Cout, N.ptr(ga), N.ptr(be), 1e-5, 0.1, N.ptr(rm), N.ptr(rv),
+                                        N.ptr(mean), N.ptr(invstd), N.ptr(scale), N.ptr(shift), T.S()))
+        assert float((mean.cpu().double() - mean64).abs().max()) <= 2e-6 * float(y64.abs().max()), f"tile {tile} mean"
+        inv64 = 1 / torch.sqrt(var64 + 1e-5)
+        assert float(((invstd.cpu().double() - inv64) / inv64).abs().max()) <= 2e-5, f"tile {tile} invstd"
+        assert torch.allclose(rv.cpu().double(), 0.9 + 0.1 * var64 * M / (M - 1), rtol=2e-5)
+        assert torch.allclose(scale, ga * invstd) and torch.allclose(shift, be - mean * scale, atol=1e-6)
