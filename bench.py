@@ -127,8 +127,10 @@ def main():
     opt = optim.Adam(model.parameters(), lr=1e-3)
     images, labels = synthetic_batch(B, C, wl["p_neg"], wl["loss"], dev, 42 + rank)
     if wl["loss"] == "garbage":
-        from oracle import losses_oracle as LO  # class weights of the synthetic label histogram (host-side data prep)
-        loss_fn = GarbageLoss(LO.class_weights(torch.where(labels.cpu() == C - 1, -1, labels.cpu())))
+        from openset_imagenet.dataset import LabelTable  # class weights of the synthetic label histogram (dataset.py:77-86)
+        table = LabelTable(torch.where(labels.cpu() == C - 1, -1, labels.cpu()).numpy())
+        table.replace_negative_label()
+        loss_fn = GarbageLoss(table.calculate_class_weights())
     else:
         loss_fn = EntropicOpensetLoss(C, 1.0)
 
@@ -194,9 +196,20 @@ def main():
         if prof:
             conv_ms = sum(prof[k]["ms_per_step"] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
             achieved = B * CONV_GFLOP_PER_IMAGE * 1e9 / (conv_ms * 1e-3) / 1e12
+            # HBM-side traffic of the conv kernels per step cannot be read from inside the process; it is the rocprofv3 PMC
+            # measurement of this same command committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE, KiB units, the x2 is the
+            # gfx950 wide-read correction of MI355X_MICROARCH.md, validated on the Adam kernel's known 380/285 MB).
+            traffic, tpath = None, os.path.join(ROOT, "profiles", "r01_hbm_traffic_per_step.json")
+            if os.path.isfile(tpath) and B == 128 and args.workload == "p2":
+                t = json.load(open(tpath))
+                traffic = round(sum(t[k]["fetch_GB_x2_wide_read_correction"] + t[k]["write_GB"]
+                                    for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) * 1e9)
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "bytes per step at the L2<->fabric boundary for the three conv kernel classes, from "
+                                "profiles/r01_hbm_traffic_per_step.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes); "
+                                "algorithmic minimum ~36e9 (each conv input/output once fwd, dY+W / dY+X bwd)",
                 "kernel": "implicit-GEMM conv (k_conv_fwd + k_conv_dgrad + k_conv_wgrad incl. split-K reduce), fp32 MFMA 32x32x2",
                 "how": f"24.287 GFLOP/img x {B} img per step / summed HIP-event duration of the conv launches per step ({conv_ms:.2f} ms), "
                        f"events recorded on the launch stream over {psteps} instrumented steps run straight after the timed region "

@@ -118,6 +118,11 @@ int osi_loss_fwd_bwd(int mode, const float* logits, const long long* target, int
                      long long ignore_index, const float* class_weights, const float* features, int F, float xi, float alpha,
                      float* loss, float* dlogits, float* dfeatures, osi_stream_t stream);
 int osi_softmax(const float* logits, float* out, int B, int C, osi_stream_t stream); /* train.py:177 */
+/* validation confidences of metrics.py:8-42 accumulated on the device across batches: acc4 (double[4], caller-zeroed) +=
+ * {sum known score[y], #known, sum negatives (1 + offset - max score[:last_valid_class]), #negatives}.
+ * last_valid_class: 0 = all columns (Python None), negative = Python negative slice end (-1: drop the background column). */
+int osi_confidence_accumulate(const float* logits, const long long* target, int B, int C, float offset, long long unknown_class,
+                              int last_valid_class, double* acc4, osi_stream_t stream);
 
 /* ---- optimizer + arena utilities (train.py:356-359 construction, train.py:127,139 zero_grad/step) --- */
 int osi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,

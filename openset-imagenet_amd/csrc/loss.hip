@@ -125,9 +125,51 @@ __global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ z, fl
     for (int c = lane; c < C; c += 64) out[(size_t)i * C + c] = expf(zr[c] - mx) / se;
 }
 
+// Validation confidences (reference openset_imagenet/metrics.py:8-42, called from train.py:187-192), accumulated on the device
+// over the batches of an epoch instead of materialising the [N_val, C] score matrix: acc[0] += sum of softmax(z)[y] over known
+// rows (y >= 0, y != unknown_class), acc[1] += their count, acc[2] += sum over rows with y == unknown_class of
+// (1 + offset - max_{c < n_valid} softmax(z)[c]), acc[3] += their count. One workgroup, fixed order, double accumulators.
+__global__ __launch_bounds__(LOSS_THREADS) void k_confidence(const float* __restrict__ z, const long long* __restrict__ y, int B, int C,
+                                                            float offset, long long unknown_class, int n_valid, double* acc) {
+    __shared__ double red[4][LOSS_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double ks = 0, kc = 0, ns = 0, nc = 0;
+    for (int i = wave; i < B; i += LOSS_WAVES) {
+        const float* zr = z + (size_t)i * C;
+        const long long yi = y[i];
+        float mx = -__builtin_inff(), mv = -__builtin_inff();
+        for (int c = lane; c < C; c += 64) { float v = zr[c]; mx = fmaxf(mx, v); if (c < n_valid) mv = fmaxf(mv, v); }
+        mx = wave_max(mx); mv = wave_max(mv);
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += expf(zr[c] - mx);
+        se = wave_sum(se);
+        if (yi == unknown_class) { ns += (double)(1.0f + offset - expf(mv - mx) / se); nc += 1; }
+        else if (yi >= 0 && yi < C) { ks += (double)(expf(zr[yi] - mx) / se); kc += 1; }
+    }
+    if (lane == 0) { red[0][wave] = ks; red[1][wave] = kc; red[2][wave] = ns; red[3][wave] = nc; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double t = 0;
+        for (int k = 0; k < LOSS_WAVES; ++k) t += red[threadIdx.x][k];
+        acc[threadIdx.x] += t;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int osi_confidence_accumulate(const float* logits, const long long* target, int B, int C, float offset, long long unknown_class,
+                              int last_valid_class, double* acc4, osi_stream_t stream) {
+    OSI_REQUIRE(logits && target && acc4 && B > 0 && C > 0);
+    // python slicing scores[:, :last_valid_class]: None (encoded as 0 here) = all C columns, negative = C + last_valid_class
+    const int n_valid = last_valid_class == 0 ? C : (last_valid_class < 0 ? C + last_valid_class : last_valid_class);
+    OSI_REQUIRE(n_valid > 0 && n_valid <= C);
+    hipLaunchKernelGGL(k_confidence, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, logits, target, B, C, offset,
+                       unknown_class, n_valid, acc4);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
 
 int osi_loss_fwd_bwd(int mode, const float* logits, const long long* target, int B, int C, float unk_weight,
                      long long ignore_index, const float* class_weights, const float* features, int F, float xi, float alpha,

@@ -119,3 +119,63 @@ def train(model, data_loader, optimizer, loss_fn, trackers, cfg):
     if pending:
         for value, n in zip(torch.stack(pending).cpu().tolist(), counts):
             trackers["j"].update(value, n)
+
+
+def validate(model, data_loader, loss_fn, n_classes, trackers, cfg):
+    """Validation loop with the reference's contract (train.py:142-196): eval-mode forward under no_grad, loss per batch into
+    trackers["j"], known / negative confidences into trackers["conf_kn"] / ["conf_unk"].
+
+    The reference fills an [N_val, C] softmax matrix on the device and reduces it with metrics.confidence() in Python loops
+    (`sum(known)`, metrics.py:27-28). Here softmax + confidence are one kernel per batch that accumulates the four sums in a
+    double[4] on the device (osi_confidence_accumulate); nothing is synchronised until the end of the loop."""
+    from . import _native as N
+    for metric in trackers.values():
+        metric.reset()
+    if cfg.loss.type == "garbage":
+        min_unk_score, unknown_class, last_valid = 0.0, n_classes - 1, -1
+    else:
+        min_unk_score, unknown_class, last_valid = 1.0 / n_classes, -1, 0   # 0 encodes Python's None (all columns)
+    wants_features = isinstance(loss_fn, _losses.ObjectosphereLoss)
+    model.eval()
+    losses, counts = [], []
+    acc = None
+    with torch.no_grad():
+        for images, labels in data_loader:
+            images = tools.device(images)
+            labels = tools.device(labels)
+            logits, features = model(images)
+            j = loss_fn(logits, labels, features) if wants_features else loss_fn(logits, labels)
+            losses.append(j)
+            counts.append(labels.shape[0])
+            if acc is None:
+                acc = torch.zeros(4, dtype=torch.float64, device=logits.device)
+            lg = logits.contiguous()
+            N.check(N.lib().osi_confidence_accumulate(N.ptr(lg), N.ptr(labels), lg.shape[0], lg.shape[1], float(min_unk_score),
+                                                      int(unknown_class), int(last_valid), N.ptr(acc), N.stream_of(lg)),
+                    "osi_confidence_accumulate")
+    if not losses:
+        return
+    for value, n in zip(torch.stack(losses).cpu().tolist(), counts):
+        trackers["j"].update(value, n)
+    kn_sum, kn_count, neg_sum, neg_count = acc.cpu().tolist()
+    if kn_count:
+        trackers["conf_kn"].update(kn_sum / kn_count, int(kn_count))
+    if neg_count:
+        trackers["conf_unk"].update(neg_sum / neg_count, int(neg_count))
+
+
+def get_arrays(model, loader):
+    """Targets, logits, deep features and softmax scores of a whole dataset as numpy arrays (reference train.py:200-234);
+    everything is gathered on the device and copied to the host once."""
+    model.eval()
+    t, lg, ft, sc = [], [], [], []
+    with torch.no_grad():
+        for images, labels in loader:
+            labels = tools.device(labels)
+            logit, feature = model(tools.device(images))
+            t.append(labels)
+            lg.append(logit)
+            ft.append(feature)
+            sc.append(_losses.softmax(logit))
+    cat = lambda xs: torch.cat(xs).cpu().numpy()
+    return cat(t).astype(np.float32), cat(lg), cat(ft), cat(sc)
