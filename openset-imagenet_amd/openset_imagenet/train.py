@@ -179,3 +179,141 @@ def get_arrays(model, loader):
             sc.append(_losses.softmax(logit))
     cat = lambda xs: torch.cat(xs).cpu().numpy()
     return cat(t).astype(np.float32), cat(lg), cat(ft), cat(sc)
+
+
+def _image_loader(csv_file, imagenet_path, train, loss_type):
+    """ImagenetDataset of the reference (dataset.py:10-54) with its transforms (train.py:259-268), PIL + torch only
+    (torchvision is not a dependency of this build). Host-side input pipeline: outside the GPU hot path."""
+    import pandas as pd
+    from PIL import Image
+    from .dataset import LabelTable
+
+    class _DS(torch.utils.data.Dataset):
+        def __init__(self):
+            self.frame = pd.read_csv(csv_file, header=None)
+            self.table = LabelTable(self.frame[1].to_numpy())
+            if loss_type == "garbage":
+                self.table.replace_negative_label()
+                self.frame[1] = self.table.labels
+            elif loss_type == "softmax" and train:
+                self.frame = self.frame[self.frame[1] >= 0].reset_index(drop=True)
+                self.table.remove_negative_label()
+            self.root = pathlib.Path(imagenet_path)
+
+        def __len__(self):
+            return len(self.frame)
+
+        def __getitem__(self, i):
+            path, label = self.frame.iloc[i]
+            img = Image.open(self.root / path).convert("RGB")
+            w, h = img.size
+            s = 256 / min(w, h)
+            img = img.resize((max(256, round(w * s)), max(256, round(h * s))), Image.BILINEAR)     # Resize(256)
+            w, h = img.size
+            if train:                                                                          # RandomCrop(224) + flip(0.5)
+                x0, y0 = random.randint(0, w - 224), random.randint(0, h - 224)
+            else:                                                                              # CenterCrop(224)
+                x0, y0 = (w - 224) // 2, (h - 224) // 2
+            img = img.crop((x0, y0, x0 + 224, y0 + 224))
+            if train and random.random() < 0.5:
+                img = img.transpose(Image.FLIP_LEFT_RIGHT)
+            x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)  # ToTensor()
+            return x, torch.as_tensor(int(label), dtype=torch.int64)
+    return _DS()
+
+
+def worker(cfg):
+    """Creates datasets, model, loss, optimizer, runs the epoch loop with checkpoints — the reference's worker()
+    (train.py:237-482) reduced to what drives the hot path. Same cfg keys (config/train.yaml), same checkpoint files
+    `{name}_curr.pth` / `{name}_best.pth`, same best-score rule (conf_kn + conf_unk) and early stopping. Logging goes to the
+    `logging` module and a CSV of per-epoch scalars (loguru / TensorBoard are not dependencies of this build).
+    `cfg.data.synthetic` (new key, default absent) = number of synthetic training samples to use instead of the CSV files."""
+    import logging
+    import time
+    from .dataset import LabelTable, SyntheticImagenet
+    set_seeds(cfg.seed)
+    out_dir = pathlib.Path(cfg.output_directory)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(levelname)s: %(message)s",
+                        handlers=[logging.StreamHandler(), logging.FileHandler(out_dir / cfg.log_name, mode="w")], force=True)
+    log = logging.getLogger("openset_imagenet")
+    if cfg.gpu is not None:
+        tools.set_device_gpu(index=cfg.gpu)
+    else:
+        raise RuntimeError("No GPU device selected: the MI355X build has no CPU training path (pass -g [index])")
+
+    n_syn = getattr(cfg.data, "synthetic", None)
+    if n_syn:
+        n_known = {1: 116, 2: 30, 3: 151}[int(cfg.protocol)]
+        g = torch.Generator().manual_seed(cfg.seed)
+        def labels(n):
+            y = torch.randint(0, n_known, (n,), generator=g)
+            y[torch.rand(n, generator=g) < 0.4] = -1
+            return y
+        tables = []
+        for n, train in ((int(n_syn), True), (max(int(n_syn) // 4, cfg.batch_size), False)):
+            t = LabelTable(labels(n).numpy())
+            if cfg.loss.type == "garbage":
+                t.replace_negative_label()
+            elif cfg.loss.type == "softmax" and train:
+                t.remove_negative_label()
+            tables.append(t)
+        train_table, val_table = tables
+        train_ds, val_ds = SyntheticImagenet(train_table.labels, seed=1), SyntheticImagenet(val_table.labels, seed=2)
+    else:
+        train_file = pathlib.Path(cfg.data.train_file.format(cfg.protocol))
+        val_file = pathlib.Path(cfg.data.val_file.format(cfg.protocol))
+        if not (train_file.exists() and val_file.exists()):
+            raise FileNotFoundError("train/validation file does not exist")
+        train_ds = _image_loader(train_file, cfg.data.imagenet_path, True, cfg.loss.type)
+        val_ds = _image_loader(val_file, cfg.data.imagenet_path, False, cfg.loss.type)
+        train_table = train_ds.table
+    train_loader = torch.utils.data.DataLoader(train_ds, batch_size=cfg.batch_size, shuffle=True, num_workers=cfg.workers, pin_memory=True)
+    val_loader = torch.utils.data.DataLoader(val_ds, batch_size=cfg.batch_size, num_workers=cfg.workers, pin_memory=True)
+
+    # number of classes / loss (train.py:329-347)
+    if cfg.loss.type == "entropic":
+        n_classes = train_table.label_count - 1 if train_table.has_negatives() else train_table.label_count
+    else:
+        n_classes = train_table.label_count
+    class_weights = train_table.calculate_class_weights() if cfg.loss.type == "garbage" else None
+    loss_fn = build_loss(cfg, n_classes, class_weights)
+    model = build_model(cfg, n_classes)
+    opt = build_optimizer(cfg, model)
+    scheduler = torch.optim.lr_scheduler.StepLR(opt, step_size=cfg.opt.decay, gamma=cfg.opt.gamma) if cfg.opt.decay > 0 else None
+
+    best_score, start_epoch = 0.0, 0
+    if cfg.checkpoint is not None:
+        if cfg.train_mode == "finetune":
+            load_checkpoint(model, cfg.checkpoint)
+        else:
+            start_epoch, best_score = load_checkpoint(model, cfg.checkpoint, opt, scheduler)
+        log.info(f"Loaded {cfg.checkpoint} at epoch {start_epoch}")
+    t_metrics = {"j": _losses.AverageMeter()}
+    v_metrics = {"j": _losses.AverageMeter(), "conf_kn": _losses.AverageMeter(), "conf_unk": _losses.AverageMeter()}
+    early = _losses.EarlyStopping(patience=cfg.patience) if cfg.patience > 0 else None
+    scalars = open(out_dir / f"scalars-{cfg.log_name}.csv", "w")
+    scalars.write("epoch,train/loss,val/loss,val/conf_kn,val/conf_unk\n")
+    log.info(f"Training: protocol {cfg.protocol}, loss {cfg.loss.type}, {n_classes} classes, {len(train_ds)} / {len(val_ds)} samples")
+    for epoch in range(start_epoch, cfg.epochs):
+        t0 = time.time()
+        train(model, train_loader, opt, loss_fn, t_metrics, cfg)
+        t1 = time.time()
+        validate(model, val_loader, loss_fn, n_classes, v_metrics, cfg)
+        curr_score = v_metrics["conf_kn"].avg + v_metrics["conf_unk"].avg
+        if scheduler is not None:
+            scheduler.step()
+        scalars.write(f"{epoch},{t_metrics['j'].avg},{v_metrics['j'].avg},{v_metrics['conf_kn'].avg},{v_metrics['conf_unk'].avg}\n")
+        scalars.flush()
+        log.info(f"ep:{epoch} train:{t_metrics} val:{v_metrics} t:{t1 - t0:.1f}s v:{time.time() - t1:.1f}s")
+        save_checkpoint(out_dir / (cfg.name + "_curr.pth"), model, epoch, opt, curr_score, scheduler)
+        if curr_score > best_score:
+            best_score = curr_score
+            save_checkpoint(out_dir / (cfg.name + "_best.pth"), model, epoch, opt, best_score, scheduler)
+        if early is not None:
+            early(metrics=curr_score, loss=False)
+            if early.early_stop:
+                log.info("early stop")
+                break
+    scalars.close()
+    return best_score

@@ -106,3 +106,21 @@ def test_config_meters_and_loss_factory(tmp_path):
     with pytest.raises(ValueError):
         build_loss(cfg, 30)
     assert tools.device(torch.zeros(1)).device.type == "cpu" and tools.get_device().type == "cpu"
+
+
+def test_cli_arguments_and_label_table():
+    from openset_imagenet.script.train import get_args
+    from openset_imagenet.dataset import LabelTable, SyntheticImagenet
+    a = get_args(["cfg.yaml", "2", "-g", "--nice", "0"])
+    assert a.gpu == 0 and a.protocol == 2 and str(a.output_directory) == "."       # bare -g selects GPU 0 (reference bug fixed)
+    assert get_args(["cfg.yaml", "1", "--nice", "0"]).gpu is None
+    t = LabelTable([-1, -1, -1, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2])
+    assert t.has_negatives() and t.label_count == 4
+    t.replace_negative_label()
+    assert np.allclose(t.calculate_class_weights().numpy(), [1.125, 0.9, 0.75, 1.5])
+    t2 = LabelTable([-1, 0, 1, 1]); t2.remove_negative_label()
+    assert t2.label_count == 2 and list(t2.labels) == [0, 1, 1]
+    ds = SyntheticImagenet([3, -1], image_size=32)
+    x, y = ds[1]
+    assert x.shape == (3, 32, 32) and x.dtype == torch.float32 and 0 <= float(x.min()) and float(x.max()) < 1 and int(y) == -1
+    assert torch.equal(ds[1][0], x)
