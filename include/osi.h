@@ -56,6 +56,25 @@ int osi_conv_fwd_bnstats(const osi_conv_desc* d, const float* x, const float* w,
 /* dx (+)= conv2d_input_grad(dy, w). accumulate != 0 adds into dx (skip-connection sum). Cout % 32 == 0, Cin % 64 == 0. */
 int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, int tile,
                    osi_stream_t stream);
+/* Input gradient with a fused epilogue: dx = relu_mask . (conv2d_input_grad(dy, w) + addend), i.e. the gradient already passed
+ * through the ReLU that produced this conv's input (bitmask written by osi_bn_apply_relu_mask); when `partials` is set the
+ * epilogue also emits, per row tile, the column sums of g, g*xhat0 and (y1 != NULL) g*xhat1 (xhat = (y - mean)*invstd) — the
+ * BatchNorm-backward reductions of the layer(s) that produced that input — as partials[3][*P][Cin], to be finished by
+ * osi_bn_backward_fused. addend may be dx. */
+typedef struct {
+    const void* relu_mask;  /* may be NULL: no mask */
+    const float* y0;        /* pre-BN tensor of the consumer BatchNorm, same shape as dx */
+    const float* mean0;     /* its batch mean [Cin] */
+    const float* invstd0;   /* its batch 1/sqrt(var + eps) [Cin] */
+    const float* y1;        /* second consumer (downsample branch) or NULL */
+    const float* mean1;
+    const float* invstd1;
+    float* partials;        /* NULL: no reductions */
+    size_t partials_bytes;  /* >= osi_conv_dgrad_fused_workspace(d) */
+} osi_dgrad_fusion;
+size_t osi_conv_dgrad_fused_workspace(const osi_conv_desc* d);
+int osi_conv_dgrad_fused(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,
+                         const osi_dgrad_fusion* f, int tile, int* P, osi_stream_t stream);
 /* dw = conv2d_weight_grad(dy, x), deterministic split-K through `ws` (size from osi_conv_wgrad_workspace). The stem writes
  * the packed [Cout][224] form; osi_stem_grad_unpack converts to [Cout][7][7][3]. */
 size_t osi_conv_wgrad_workspace(const osi_conv_desc* d);
@@ -96,6 +115,13 @@ int osi_bn_apply_relu_mask(const float* y, const float* residual, const float* s
 int osi_bn_backward_relu_mask(const float* dout, const void* relu_mask, const float* y, const float* mean, const float* invstd,
                               const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
                               size_t ws_bytes, osi_stream_t stream);
+
+/* BatchNorm backward when g (already ReLU-masked) and its reductions come from osi_conv_dgrad_fused: psum_g / psum_gx are
+ * [P][C] row-tile partials of sum g and sum g*xhat. Finishes dbeta = sum g, dgamma = sum g*xhat and applies
+ * dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)). dy may alias g. ws: osi_bn_backward_workspace(M, C) bytes. */
+int osi_bn_backward_fused(const float* g, const float* y, const float* mean, const float* invstd, const float* gamma,
+                          const float* psum_g, const float* psum_gx, int P, float* dy, float* dgamma, float* dbeta, int M, int C,
+                          void* ws, size_t ws_bytes, osi_stream_t stream);
 
 /* ---- pooling / layout (ResNet.maxpool, ResNet.avgpool, flatten; image batch of train.py:128) --- */
 int osi_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int B, int H, int W, osi_stream_t stream);

@@ -336,6 +336,24 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_final(const float* __restrict__ p
 }
 
 // dy = gamma*invstd * ( g - c1 - xhat*c2 ) ; optionally also emits g (the masked upstream gradient) for the skip path
+// Column sums of two row-major [P][C] partial matrices over row group s (blockIdx.y) -> channel-major [C][S] for k_bn_bwd_final.
+__global__ __launch_bounds__(NT) void k_colsum2_group(const float* __restrict__ a, const float* __restrict__ b, int P, int Pc, int C,
+                                                     int S, float* __restrict__ ga, float* __restrict__ gb) {
+    __shared__ float ra[16][16], rb[16][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl, s = blockIdx.y;
+    const int b0 = s * Pc, b1 = min(P, b0 + Pc);
+    float xa = 0.f, xb = 0.f;
+    if (c < C)
+        for (int r = b0 + pl; r < b1; r += 16) { xa += a[(size_t)r * C + c]; xb += b[(size_t)r * C + c]; }
+    ra[pl][cl] = xa; rb[pl][cl] = xb;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int k = 1; k < 16; ++k) { xa += ra[k][cl]; xb += rb[k][cl]; }
+        ga[(size_t)c * S + s] = xa; gb[(size_t)c * S + s] = xb;
+    }
+}
+
 template <int MODE, bool EMITG>
 __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const f32x4* dA /* may alias dy */, const void* __restrict__ msk,
                                                     const f32x4* __restrict__ y, const f32x4* __restrict__ mean,
@@ -509,6 +527,34 @@ static int bn_backward_impl(const float* dout, const void* msk, int mode, const 
     else if (mode == 1) { if (gmasked) OSI_BWD_APPLY(1, true); else OSI_BWD_APPLY(1, false); }
     else { if (gmasked) OSI_BWD_APPLY(0, true); else OSI_BWD_APPLY(0, false); }
 #undef OSI_BWD_APPLY
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+int osi_bn_backward_fused(const float* g, const float* y, const float* mean, const float* invstd, const float* gamma,
+                          const float* psum_g, const float* psum_gx, int P, float* dy, float* dgamma, float* dbeta, int M, int C,
+                          void* ws, size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(g && y && mean && invstd && gamma && psum_g && psum_gx && dy && dgamma && dbeta && ws);
+    OSI_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && P > 0);
+    int S = osi_cdiv(P, 64);
+    if (S > OSI_BN_GROUPS) S = OSI_BN_GROUPS;
+    const int Pc = osi_cdiv(P, S);
+    S = osi_cdiv(P, Pc);
+    OSI_REQUIRE(ws_bytes >= ((size_t)2 * S * C + 2 * (size_t)C) * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float* gb = (float*)ws;               // [C][S] group sums of g
+    float* gg = gb + (size_t)S * C;       // [C][S] group sums of g*xhat
+    float* c1 = gg + (size_t)S * C;
+    float* c2 = c1 + C;
+    hipLaunchKernelGGL(k_colsum2_group, dim3(osi_cdiv(C, 16), S), dim3(NT), 0, st, psum_g, psum_gx, P, Pc, C, S, gb, gg);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, (const float*)gb, (const float*)gg, S, M, C, dgamma,
+                       dbeta, c1, c2);
+    OSI_LAUNCH_CHECK();
+    const size_t n4 = (size_t)M * C / 4;
+    hipLaunchKernelGGL((k_bn_bwd_apply<0, false>), dim3(stream_grid(n4)), dim3(NT), 0, st, (const f32x4*)g, (const void*)nullptr,
+                       (const f32x4*)y, (const f32x4*)mean, (const f32x4*)invstd, (const f32x4*)gamma, (const f32x4*)c1,
+                       (const f32x4*)c2, (f32x4*)dy, (f32x4*)nullptr, n4, C / 4);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }

@@ -44,6 +44,15 @@ struct ConvP {
     int unit;             // dgrad: 1x1 stride-1 conv -> the im2col row of pixel m is row m of dY
     float* pmean;         // fwd: optional BatchNorm partials [MT][Cout] (mean, M2) written by the epilogue
     float* pm2;
+    // dgrad epilogue fusion (all optional): dx = mask(ebits) . (acc + addend); esum[0..2][eP][Cin] = per row tile column sums of
+    // g, g*ey0, g*ey1 for the BatchNorm backward of the layer(s) that consume this gradient
+    const float* addend;
+    const unsigned long long* ebits;
+    const float* ey0;
+    const float* ey1;
+    const float *emean0, *einv0, *emean1, *einv1;  // batch mean / invstd of the consumer BatchNorm(s): xhat = (y - mean) * invstd
+    float* esum;
+    int eP;
     // wgrad only
     int kchunk;       // pixels per split
     size_t slab_stride;
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
 // class only visits the filter taps that can reach it, so no MFMA work is spent on structural zeros.
 // blockIdx.y = class. GEMM N = Cin, K = (taps of the class) x Cout.
 // ======================================================================================================
-template <int WM, int WN, int NST>
+template <int WM, int WN, int NST, bool FUSED>
 __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32;
@@ -310,7 +319,14 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = mt * BM, n0 = nt * BN;
-    if (m0 >= Mc) return;
+    if (m0 >= Mc) {  // a row tile beyond this (smaller) parity class: contributes nothing, but its partial row must read as zero
+        if (p.esum && tid < BN) {
+            const size_t prow = (size_t)(cls * p.MT + mt) * p.Cin + n0 + tid, pstride = (size_t)p.eP * p.Cin;
+            p.esum[prow] = 0.f; p.esum[pstride + prow] = 0.f;
+            if (p.ey1) p.esum[2 * pstride + prow] = 0.f;
+        }
+        return;
+    }
     const int kq = tid & 7, lr = tid >> 3;
 
     // taps reaching this class: r = rb + st*jr, (h + pad - r) / st = hb - jr
@@ -398,38 +414,94 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         }
     }
 
-    // epilogue: all destination rows of a 32x32 tile are addressed first, (accumulate: loaded in one batch), then stored
+    // epilogue. Element offsets fit 31 bits (desc_ok). Rows are handled four at a time so that the fused form (addend + mask +
+    // BatchNorm reductions) keeps few values live: the register footprint of the epilogue sets the occupancy of the K loop.
+    float esg[WN], es0[WN], es1[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) { esg[n] = 0.f; es0[n] = 0.f; es1[n] = 0.f; }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-        size_t rowoff[16];
-        bool rowok[16];
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            int m = m0 + wm * 32 * WM + i * 32 + acc_row(rr, lane);
-            rowok[rr] = m < Mc;
-            uint32_t mm = rowok[rr] ? (uint32_t)m : 0u;
-            size_t pix;
-            if (st == 1) pix = mm;
-            else {
-                uint32_t b = fdiv(mm, dHW);
-                uint32_t rem = mm - b * dHW.d;
-                uint32_t h2 = fdiv(rem, dW), w2 = rem - h2 * dW.d;
-                pix = ((size_t)b * p.H + (ph + st * (int)h2)) * p.W + (pw + st * (int)w2);
+        for (int q = 0; q < 4; ++q) {   // accumulator registers 4q..4q+3 = rows 8q + 4*(lane>>5) + 0..3
+            uint32_t roff[4];
+            bool rok[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int m = m0 + wm * 32 * WM + i * 32 + acc_row(4 * q + e, lane);
+                rok[e] = m < Mc;
+                uint32_t mm = rok[e] ? (uint32_t)m : 0u;
+                uint32_t pix;
+                if (st == 1) pix = mm;
+                else {
+                    uint32_t b = fdiv(mm, dHW);
+                    uint32_t rem = mm - b * dHW.d;
+                    uint32_t h2 = fdiv(rem, dW), w2 = rem - h2 * dW.d;
+                    pix = (b * p.H + (ph + st * h2)) * p.W + (pw + st * w2);
+                }
+                roff[e] = pix * p.Cin;
             }
-            rowoff[rr] = pix * p.Cin;
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                const int col = n0 + wn * 32 * WN + n * 32 + (lane & 31);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][n][4 * q + e];
+                if (p.addend) {  // skip-connection sum (may be the output buffer itself: read-modify-write by the same lane)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rok[e] ? p.addend[roff[e] + col] : 0.f;
+                }
+                if (FUSED) {
+                    if (p.ebits) {  // ReLU mask of the activation this gradient belongs to (1 bit / element, see bn.hip)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t i4 = (roff[e] + col) >> 2;
+                            const unsigned long long w = rok[e] ? p.ebits[(size_t)(i4 >> 6) * 4 + (col & 3)] : 0ull;
+                            v[e] = (w >> (i4 & 63)) & 1 ? v[e] : 0.f;
+                        }
+                    }
+                    if (p.esum) {   // BatchNorm-backward partial sums of the consumer(s): sum g, sum g*xhat0 [, sum g*xhat1]
+                        const float mu0 = p.emean0[col], is0 = p.einv0[col];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gv = rok[e] ? v[e] : 0.f;
+                            esg[n] += gv;
+                            es0[n] += gv * ((rok[e] ? p.ey0[roff[e] + col] : mu0) - mu0) * is0;
+                        }
+                        if (p.ey1) {
+                            const float mu1 = p.emean1[col], is1 = p.einv1[col];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                es1[n] += (rok[e] ? v[e] : 0.f) * ((rok[e] ? p.ey1[roff[e] + col] : mu1) - mu1) * is1;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (rok[e]) p.y[roff[e] + col] = v[e];
+            }
         }
+    }
+    if (FUSED && p.esum) {  // lane halves, then the two wave rows through LDS: one row of partials per workgroup
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
-            const int col = n0 + wn * 32 * WN + n * 32 + (lane & 31);
-            if (p.accumulate) {
-                f32x16 old;
+            esg[n] += __shfl_xor(esg[n], 32, 64); es0[n] += __shfl_xor(es0[n], 32, 64); es1[n] += __shfl_xor(es1[n], 32, 64);
+        }
+        __syncthreads();
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) old[rr] = rowok[rr] ? p.y[rowoff[rr] + col] : 0.f;
-                acc[i][n] += old;
+        for (int n = 0; n < WN; ++n)
+            if (lane < 32) {
+                float* dst = smem + (wm * BN + wn * 32 * WN + n * 32 + lane) * 3;
+                dst[0] = esg[n]; dst[1] = es0[n]; dst[2] = es1[n];
             }
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr)
-                if (rowok[rr]) p.y[rowoff[rr] + col] = acc[i][n][rr];
+        __syncthreads();
+        if (tid < BN) {
+            const float* a = smem + tid * 3;
+            const float* b = smem + (BN + tid) * 3;
+            const size_t prow = (size_t)(cls * p.MT + mt) * p.Cin + n0 + tid;
+            const size_t pstride = (size_t)p.eP * p.Cin;
+            p.esum[prow] = a[0] + b[0];
+            p.esum[pstride + prow] = a[1] + b[1];
+            if (p.ey1) p.esum[2 * pstride + prow] = a[2] + b[2];
         }
     }
 }
@@ -631,8 +703,8 @@ static int launch_fwd(ConvP p, hipStream_t st) {
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
-template <int WM, int WN, int NST = 2>
-static int launch_dgrad(ConvP p, hipStream_t st) {
+template <int WM, int WN, int NST, bool FUSED>
+static int launch_dgrad_impl(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int s = p.stride;
     for (int ph = 0; ph < s; ++ph)
@@ -646,11 +718,20 @@ static int launch_dgrad(ConvP p, hipStream_t st) {
     p.MT = osi_cdiv((long)p.B * Hc * Wc, BM); p.NT = p.Cin / BN;
     size_t smem = 2 * (size_t)(BM * LDR + BK * (BN + 4)) * sizeof(float);
     smem = smem / 2 * NST;
-    if (int e = set_smem(k_conv_dgrad<WM, WN, NST>, smem)) return e;
+    if (int e = set_smem(k_conv_dgrad<WM, WN, NST, FUSED>, smem)) return e;
     int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
-    hipLaunchKernelGGL((k_conv_dgrad<WM, WN, NST>), dim3(grid, s * s), dim3(256), smem, st, p, Hc, Wc);
+    hipLaunchKernelGGL((k_conv_dgrad<WM, WN, NST, FUSED>), dim3(grid, s * s), dim3(256), smem, st, p, Hc, Wc);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
+}
+template <int WM, int WN, int NST = 2>
+static int launch_dgrad(ConvP p, hipStream_t st) {
+    // the fused epilogue (mask / BatchNorm reductions) is its own instantiation so that plain launches keep the small one
+    if (p.ebits || p.esum) {
+        if (NST != 1 || WM != 1) return OSI_ERR_ARG;   // fusion is built for the single-buffered 64-row tiles the executor uses
+        return launch_dgrad_impl<1, WN, 1, true>(p, st);
+    }
+    return launch_dgrad_impl<WM, WN, NST, false>(p, st);
 }
 template <int WM, int WN, bool STEM, int NST = 2>
 static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
@@ -755,16 +836,54 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
     }
 }
 
+static int dgrad_rows(int tile) {
+    return (tile == OSI_TILE_128x128 || tile == OSI_TILE_128x64 || tile == OSI_TILE_128x128_S1 || tile == OSI_TILE_128x64_S1) ? 128 : 64;
+}
+static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,
+                           const osi_dgrad_fusion* f, int tile, int* P, osi_stream_t stream);
+
 int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, int tile,
                    osi_stream_t stream) {
+    return conv_dgrad_impl(d, dy, w, dx, accumulate ? dx : nullptr, nullptr, tile, nullptr, stream);
+}
+
+size_t osi_conv_dgrad_fused_workspace(const osi_conv_desc* d) {
+    if (!desc_ok(d)) return 0;
+    const int s = d->stride;
+    const long mt = osi_cdiv((long)d->B * osi_cdiv(d->H, s) * osi_cdiv(d->W, s), 64);
+    return (size_t)3 * s * s * mt * d->Cin * sizeof(float);
+}
+
+int osi_conv_dgrad_fused(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,
+                         const osi_dgrad_fusion* f, int tile, int* P, osi_stream_t stream) {
+    OSI_REQUIRE(f && P);
+    return conv_dgrad_impl(d, dy, w, dx, addend, f, tile, P, stream);
+}
+
+static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,
+                           const osi_dgrad_fusion* f, int tile, int* P, osi_stream_t stream) {
     OSI_REQUIRE(desc_ok(d) && dy && w && dx);
     OSI_REQUIRE(!is_stem(d));  // the image needs no gradient (train.py:128-139: input is a leaf without grad)
     OSI_REQUIRE(d->Cout % BK == 0 && d->Cin % 64 == 0 && d->stride <= 2);
     hipStream_t st = (hipStream_t)stream;
     ConvP p = make_p(d);
-    p.x = dy; p.w = w; p.y = dx; p.accumulate = accumulate;
+    p.x = dy; p.w = w; p.y = dx; p.addend = addend;
     if (tile == OSI_TILE_AUTO)  // measured (see osi_conv_fwd): 64 rows x the widest column tile the input channels allow
         tile = d->Cin % 128 == 0 ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
+    if (f) {
+        OSI_REQUIRE(f->relu_mask || !f->partials);
+        p.ebits = (const unsigned long long*)f->relu_mask;
+        if (f->partials) {
+            OSI_REQUIRE(f->y0 && f->mean0 && f->invstd0 && (!f->y1 || (f->mean1 && f->invstd1)));
+            p.emean0 = f->mean0; p.einv0 = f->invstd0; p.emean1 = f->mean1; p.einv1 = f->invstd1;
+            const int s = d->stride;
+            const int mt = osi_cdiv((long)d->B * osi_cdiv(d->H, s) * osi_cdiv(d->W, s), dgrad_rows(tile));
+            p.eP = s * s * mt;
+            OSI_REQUIRE(f->partials_bytes >= (size_t)3 * p.eP * d->Cin * sizeof(float));
+            p.ey0 = f->y0; p.ey1 = f->y1; p.esum = f->partials;
+            *P = p.eP;
+        }
+    }
     switch (tile) {
         case OSI_TILE_128x128: OSI_REQUIRE(d->Cin % 128 == 0); return launch_dgrad<2, 2>(p, st);
         case OSI_TILE_128x64: return launch_dgrad<2, 1>(p, st);

@@ -66,7 +66,7 @@ struct osi_resnet50 {
     // stem
     int Hs, Ws, Hp, Wp;              // stem conv output, maxpool output
     size_t x4, wpack, gpack, a_pool, pool_idx, pooled, feat, logits_ws;
-    size_t bn_ws, bn_ws_bytes, wg_ws, wg_ws_bytes;
+    size_t bn_ws, bn_ws_bytes, wg_ws, wg_ws_bytes, dg_ws, dg_ws_bytes;
     static constexpr int NSCR = 12;   // scratch activations-gradient buffers (each = largest activation)
     size_t scratch[NSCR], scratch_floats;
     size_t dfeat, dpooled;
@@ -78,6 +78,8 @@ struct osi_resnet50 {
     bool fwd_done = false;
     int next_stage = 0;
     int cur_grad = -1;               // scratch index holding the upstream gradient between stages
+    bool go_fused = false;           // cur_grad is already ReLU-masked and its BatchNorm reductions wait in dg_ws
+    int fused_P = 0;                 // row tiles of the partials in dg_ws
     std::vector<int> free_list;
     // optional HIP-event instrumentation: one event after every op, tagged with the op's class
     bool prof_on = false;
@@ -233,7 +235,7 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
     n->dfeat = n->ws_alloc((size_t)B * fc_dim);
     n->dpooled = n->ws_alloc((size_t)B * 2048);
     // scratch sizing
-    size_t maxact = 0, bnws = 0, wgws = 0;
+    size_t maxact = 0, bnws = 0, wgws = 0, dgws = 0;
     for (auto& c : n->convs) {
         size_t e = (size_t)c.d.B * c.d.Ho * c.d.Wo * c.d.Cout;
         if (e > maxact) maxact = e;
@@ -246,9 +248,11 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
         if (b3 > bnws) bnws = b3;
         size_t wg = osi_conv_wgrad_workspace(&c.d);
         if (wg > wgws) wgws = wg;
+        if (!(c.d.Cin == 4 && c.d.R == 7)) { size_t dg = osi_conv_dgrad_fused_workspace(&c.d); if (dg > dgws) dgws = dg; }
     }
     n->bn_ws_bytes = bnws; n->bn_ws = n->ws_alloc(bnws / 4 + 4);
     n->wg_ws_bytes = wgws; n->wg_ws = n->ws_alloc(wgws / 4 + 4);
+    n->dg_ws_bytes = dgws; n->dg_ws = n->ws_alloc(dgws / 4 + 4);
     n->scratch_floats = maxact;
     for (int i = 0; i < osi_resnet50::NSCR; ++i) n->scratch[i] = n->ws_alloc(maxact);
     *out = n;
@@ -441,6 +445,131 @@ static int bn_conv_wgrad(osi_resnet50* n, int ci, const float* params, float* gr
     return wgrad(n, ci, grads, ws, gi, conv_in, st);
 }
 
+// BatchNorm backward of conv `ci` from a gradient buffer that the producing dgrad epilogue already ReLU-masked, with the
+// reductions waiting in dg_ws (column `which` = 0: main branch, 1: downsample branch). dy goes to buffer `dyi` (may equal gi).
+static int bn_bwd_fused(osi_resnet50* n, int ci, const float* params, float* grads, float* ws, int gi, int dyi, int which,
+                        hipStream_t st) {
+    Conv& c = n->convs[ci];
+    BN& b = n->bns[c.bn];
+    const float* psum_g = ws + n->dg_ws;
+    const float* psum_gx = psum_g + (size_t)(1 + which) * n->fused_P * b.C;
+    OSI_TRY(osi_bn_backward_fused(ws + n->scratch[gi], ws + c.y, ws + b.mean, ws + b.invstd, params + b.g_off, psum_g, psum_gx,
+                                  n->fused_P, ws + n->scratch[dyi], grads + b.g_off, grads + b.b_off, b.M, b.C, ws + n->bn_ws,
+                                  n->bn_ws_bytes, st));
+    n->mark(OSI_PROF_BN_BWD, st);
+    return OSI_OK;
+}
+
+// dgrad of conv `ci` (dy in buffer dyi) into buffer dxi, adding buffer addi (-1: none), with the epilogue fused for the layer
+// that produced this conv's input: its ReLU bitmask and the BatchNorm reductions of conv `pc` (and `pd`, the downsample twin).
+static int dgrad_fused(osi_resnet50* n, int ci, const float* params, float* ws, int dyi, int dxi, int addi, int pc, int pd,
+                       hipStream_t st) {
+    Conv& c = n->convs[ci];
+    Conv& p0 = n->convs[pc];
+    BN& b0 = n->bns[p0.bn];
+    osi_dgrad_fusion f{};
+    f.relu_mask = ws + p0.mask;
+    f.y0 = ws + p0.y; f.mean0 = ws + b0.mean; f.invstd0 = ws + b0.invstd;
+    if (pd >= 0) {
+        Conv& p1 = n->convs[pd];
+        BN& b1 = n->bns[p1.bn];
+        f.y1 = ws + p1.y; f.mean1 = ws + b1.mean; f.invstd1 = ws + b1.invstd;
+    }
+    f.partials = ws + n->dg_ws; f.partials_bytes = n->dg_ws_bytes;
+    int P = 0;
+    OSI_TRY(osi_conv_dgrad_fused(&c.d, ws + n->scratch[dyi], params + c.w_off, ws + n->scratch[dxi],
+                                 addi >= 0 ? ws + n->scratch[addi] : nullptr, &f, OSI_TILE_AUTO, &P, st));
+    n->fused_P = P;
+    n->mark(OSI_PROF_CONV_DGRAD, st);
+    return OSI_OK;
+}
+
+// One bottleneck block of the backward pass. On entry n->cur_grad holds the gradient w.r.t. the block output: raw (stage entry
+// from the average pool) or, when n->go_fused, already masked by the block's final ReLU with the bn3 / downsample-BN reductions
+// in dg_ws (left there by the conv1 dgrad epilogue of the block above).
+static int block_backward(osi_resnet50* n, int bi, const float* params, float* grads, float* ws, hipStream_t st) {
+    Block& k = n->blocks[bi];
+    auto S = [&](int i) { return ws + n->scratch[i]; };
+    Conv &c1 = n->convs[k.c1], &c2 = n->convs[k.c2], &c3 = n->convs[k.c3];
+    const float* x = ws + k.x_in;
+    const bool has_ds = k.ds >= 0;
+    int go = n->cur_grad;
+    int d3 = -1, dxbase = -1;
+    if (n->go_fused) {
+        if (has_ds) {
+            Conv& cd = n->convs[k.ds];
+            int t1 = n->take(st);
+            if (t1 < 0) return OSI_ERR_STATE;
+            OSI_TRY(bn_bwd_fused(n, k.ds, params, grads, ws, go, t1, 1, st));
+            OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
+            dxbase = n->take(st);
+            if (dxbase < 0) return OSI_ERR_STATE;
+            OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dxbase), 0, OSI_TILE_AUTO, st));
+            n->mark(OSI_PROF_CONV_DGRAD, st);
+            n->give(t1);
+        }
+        d3 = n->take(st);
+        if (d3 < 0) return OSI_ERR_STATE;
+        OSI_TRY(bn_bwd_fused(n, k.c3, params, grads, ws, go, d3, 0, st));
+        if (has_ds) n->give(go);
+        else dxbase = go;          // identity skip: the masked gradient itself continues to the block input
+    } else {
+        dxbase = n->take(st);
+        if (dxbase < 0) return OSI_ERR_STATE;
+        if (has_ds) {
+            Conv& cd = n->convs[k.ds];
+            BN& bd = n->bns[cd.bn];
+            int t1 = n->take(st);
+            if (t1 < 0) return OSI_ERR_STATE;
+            OSI_TRY(osi_bn_backward_relu_mask(S(go), ws + c3.mask, ws + cd.y, ws + bd.mean, ws + bd.invstd, params + bd.g_off,
+                                              S(t1), nullptr, grads + bd.g_off, grads + bd.b_off, bd.M, bd.C, ws + n->bn_ws,
+                                              n->bn_ws_bytes, st));
+            n->mark(OSI_PROF_BN_BWD, st);
+            OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
+            OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dxbase), 0, OSI_TILE_AUTO, st));
+            n->mark(OSI_PROF_CONV_DGRAD, st);
+            n->give(t1);
+        }
+        BN& b3 = n->bns[c3.bn];
+        OSI_TRY(osi_bn_backward_relu_mask(S(go), ws + c3.mask, ws + c3.y, ws + b3.mean, ws + b3.invstd, params + b3.g_off, S(go),
+                                          has_ds ? nullptr : S(dxbase), grads + b3.g_off, grads + b3.b_off, b3.M, b3.C,
+                                          ws + n->bn_ws, n->bn_ws_bytes, st));
+        n->mark(OSI_PROF_BN_BWD, st);
+        d3 = go;
+    }
+    // conv3 -> (mask a2, bn2) -> conv2 -> (mask a1, bn1) -> conv1
+    OSI_TRY(wgrad(n, k.c3, grads, ws, d3, ws + c2.a, st));
+    int t2 = n->take(st);
+    if (t2 < 0) return OSI_ERR_STATE;
+    OSI_TRY(dgrad_fused(n, k.c3, params, ws, d3, t2, -1, k.c2, -1, st));
+    n->give(d3);
+    OSI_TRY(bn_bwd_fused(n, k.c2, params, grads, ws, t2, t2, 0, st));
+    OSI_TRY(wgrad(n, k.c2, grads, ws, t2, ws + c1.a, st));
+    int t3 = n->take(st);
+    if (t3 < 0) return OSI_ERR_STATE;
+    OSI_TRY(dgrad_fused(n, k.c2, params, ws, t2, t3, -1, k.c1, -1, st));
+    n->give(t2);
+    OSI_TRY(bn_bwd_fused(n, k.c1, params, grads, ws, t3, t3, 0, st));
+    OSI_TRY(wgrad(n, k.c1, grads, ws, t3, x, st));
+    if (bi > 0) {
+        // the block input is the previous block's output: fuse that block's final ReLU mask and its bn3 (+ downsample BN) reductions
+        Block& pk = n->blocks[bi - 1];
+        int dxn = has_ds ? dxbase : n->take(st);   // downsample case: add in place (each lane reads then writes its own element)
+        if (dxn < 0) return OSI_ERR_STATE;
+        OSI_TRY(dgrad_fused(n, k.c1, params, ws, t3, dxn, dxbase, pk.c3, pk.ds, st));
+        if (dxn != dxbase) n->give(dxbase);
+        n->cur_grad = dxn;
+        n->go_fused = true;
+    } else {
+        OSI_TRY(osi_conv_dgrad(&c1.d, S(t3), params + c1.w_off, S(dxbase), 1, OSI_TILE_AUTO, st));
+        n->mark(OSI_PROF_CONV_DGRAD, st);
+        n->cur_grad = dxbase;
+        n->go_fused = false;
+    }
+    n->give(t3);
+    return OSI_OK;
+}
+
 int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, void* workspace, const float* dlogits,
                           const float* dfeatures, int stage_lo, int stage_hi, osi_stream_t stream) {
     OSI_REQUIRE(n && params && grads && workspace);
@@ -473,50 +602,12 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             OSI_TRY(osi_avgpool_bwd(ws + n->dpooled, S(g), n->B, n->Hf * n->Wf, 2048, st));
             n->mark(OSI_PROF_OTHER, st);
             n->cur_grad = g;
+            n->go_fused = false;
         }
         for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
             Block& k = n->blocks[bi];
             if (k.stage != stage) continue;
-            int go = n->cur_grad;
-            const float* x = ws + k.x_in;
-            Conv &c1 = n->convs[k.c1], &c2 = n->convs[k.c2], &c3 = n->convs[k.c3];
-            int dx = n->take(st);
-            if (dx < 0) return OSI_ERR_STATE;
-            if (k.ds >= 0) {
-                Conv& cd = n->convs[k.ds];
-                BN& bd = n->bns[cd.bn];
-                int t1 = n->take(st);
-                if (t1 < 0) return OSI_ERR_STATE;
-                // downsample branch: g = dOut*(out>0) -> BN -> conv
-                OSI_TRY(osi_bn_backward_relu_mask(S(go), ws + c3.mask, ws + cd.y, ws + bd.mean, ws + bd.invstd, params + bd.g_off,
-                                                  S(t1), nullptr, grads + bd.g_off, grads + bd.b_off, bd.M, bd.C, ws + n->bn_ws,
-                                                  n->bn_ws_bytes, st));
-                n->mark(OSI_PROF_BN_BWD, st);
-                OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
-                OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dx), 0, OSI_TILE_AUTO, st));
-                n->mark(OSI_PROF_CONV_DGRAD, st);
-                n->give(t1);
-                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, go, nullptr, ws + c2.a, st));
-            } else {
-                // identity skip: the masked gradient itself continues to the block input
-                OSI_TRY(bn_conv_wgrad(n, k.c3, params, grads, ws, go, S(dx), ws + c2.a, st));
-            }
-            int t2 = n->take(st);
-            if (t2 < 0) return OSI_ERR_STATE;
-            OSI_TRY(osi_conv_dgrad(&c3.d, S(go), params + c3.w_off, S(t2), 0, OSI_TILE_AUTO, st));
-            n->mark(OSI_PROF_CONV_DGRAD, st);
-            n->give(go);
-            OSI_TRY(bn_conv_wgrad(n, k.c2, params, grads, ws, t2, nullptr, ws + c1.a, st));
-            int t3 = n->take(st);
-            if (t3 < 0) return OSI_ERR_STATE;
-            OSI_TRY(osi_conv_dgrad(&c2.d, S(t2), params + c2.w_off, S(t3), 0, OSI_TILE_AUTO, st));
-            n->mark(OSI_PROF_CONV_DGRAD, st);
-            n->give(t2);
-            OSI_TRY(bn_conv_wgrad(n, k.c1, params, grads, ws, t3, nullptr, x, st));
-            OSI_TRY(osi_conv_dgrad(&c1.d, S(t3), params + c1.w_off, S(dx), 1, OSI_TILE_AUTO, st));
-            n->mark(OSI_PROF_CONV_DGRAD, st);
-            n->give(t3);
-            n->cur_grad = dx;
+            OSI_TRY(block_backward(n, bi, params, grads, ws, st));
         }
         if (stage == n->n_stages - 1) {
             // maxpool + stem

@@ -40,6 +40,9 @@ _SIGS = {
     "osi_conv_fwd_bnstats": (c_int, [_PD, P, P, P, c_int, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
     "osi_bn_finalize_stats": (c_int, [P, c_size_t, c_int, c_int, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P]),
     "osi_conv_dgrad": (c_int, [_PD, P, P, P, c_int, c_int, P]),
+    "osi_conv_dgrad_fused_workspace": (c_size_t, [_PD]),
+    "osi_conv_dgrad_fused": (c_int, [_PD, P, P, P, P, P, c_int, POINTER(c_int), P]),
+    "osi_bn_backward_fused": (c_int, [P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P, c_size_t, P]),
     "osi_conv_wgrad_workspace": (c_size_t, [_PD]),
     "osi_conv_wgrad": (c_int, [_PD, P, P, P, P, c_size_t, P]),
     "osi_stem_weight_pack": (c_int, [P, P, c_int, P]),

@@ -251,11 +251,11 @@ def worker(cfg):
             y[torch.rand(n, generator=g) < 0.4] = -1
             return y
         tables = []
-        for n, train in ((int(n_syn), True), (max(int(n_syn) // 4, cfg.batch_size), False)):
+        for n, is_train in ((int(n_syn), True), (max(int(n_syn) // 4, cfg.batch_size), False)):
             t = LabelTable(labels(n).numpy())
             if cfg.loss.type == "garbage":
                 t.replace_negative_label()
-            elif cfg.loss.type == "softmax" and train:
+            elif cfg.loss.type == "softmax" and is_train:
                 t.remove_negative_label()
             tables.append(t)
         train_table, val_table = tables

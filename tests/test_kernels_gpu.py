@@ -422,3 +422,71 @@ def test_conv_epilogue_batchnorm_statistics(cuda, Cin, Cout, k, stride, H, B):
         assert float(((invstd.cpu().double() - inv64) / inv64).abs().max()) <= 2e-5, f"tile {tile} invstd"
         assert torch.allclose(rv.cpu().double(), 0.9 + 0.1 * var64 * M / (M - 1), rtol=2e-5)
         assert torch.allclose(scale, ga * invstd) and torch.allclose(shift, be - mean * scale, atol=1e-6)
+
+
+class _Fusion(ctypes.Structure):
+    _fields_ = [("relu_mask", ctypes.c_void_p), ("y0", ctypes.c_void_p), ("mean0", ctypes.c_void_p), ("invstd0", ctypes.c_void_p),
+                ("y1", ctypes.c_void_p), ("mean1", ctypes.c_void_p), ("invstd1", ctypes.c_void_p), ("partials", ctypes.c_void_p),
+                ("partials_bytes", ctypes.c_size_t)]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,H,B,two", [(64, 64, 1, 1, 14, 3, False), (128, 64, 3, 1, 9, 3, True), (256, 128, 3, 2, 9, 2, False),
+                                                     (64, 128, 1, 2, 8, 3, True), (512, 64, 1, 1, 7, 5, False)])
+def test_dgrad_fused_epilogue_vs_unfused(cuda, Cin, Cout, k, stride, H, B, two):
+    """dgrad with the fused epilogue (addend + ReLU bitmask + BatchNorm reductions) followed by osi_bn_backward_fused equals
+    plain dgrad + osi_bn_backward_relu_mask on the same data: masked gradient bit for bit, BN outputs to fp32 summation noise."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    pad = 1 if k == 3 else 0
+    g = torch.Generator().manual_seed(Cin + 3 * Cout + H)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, k, stride, pad)
+    M = B * H * H
+    dy = torch.randn(B, d.Ho, d.Wo, Cout, generator=g).to(cuda)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cout * k * k) ** 0.5).to(cuda)
+    addend = torch.randn(B, H, H, Cin, generator=g).to(cuda)
+    # the "previous layer": y0 (and y1) pre-BN tensors, their batch statistics, the ReLU bitmask of their BN output
+    ys = [(torch.randn(M, Cin, generator=g) * 2 + 1).to(cuda) for _ in range(2 if two else 1)]
+    ga = [(torch.rand(Cin, generator=g) + 0.5).to(cuda) for _ in ys]
+    be = [torch.randn(Cin, generator=g).to(cuda) for _ in ys]
+    wsb = max(L.osi_bn_workspace(M, Cin), L.osi_bn_backward_workspace(M, Cin))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    stats = []
+    for yv, gv, bv in zip(ys, ga, be):
+        st = [torch.empty(Cin, device=cuda) for _ in range(4)]
+        N.check(L.osi_bn_train_stats(N.ptr(yv), M, Cin, N.ptr(gv), N.ptr(bv), 1e-5, 0.1, None, None, *[N.ptr(t) for t in st], N.ptr(ws), wsb, T.S()))
+        stats.append(st)
+    out = torch.empty(M, Cin, device=cuda)
+    mask = torch.zeros(L.osi_bn_relu_mask_bytes(M, Cin), dtype=torch.uint8, device=cuda)
+    N.check(L.osi_bn_apply_relu_mask(N.ptr(ys[0]), None, N.ptr(stats[0][2]), N.ptr(stats[0][3]), N.ptr(out), N.ptr(mask), M, Cin, T.S()))
+    # reference: plain dgrad (+addend), then the unfused masked BatchNorm backward per consumer
+    dx_raw = addend.clone()
+    N.check(L.osi_conv_dgrad(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(dx_raw), 1, 0, T.S()))
+    ref = []
+    for yv, gv, st in zip(ys, ga, stats):
+        dyo, gm, dg, db = torch.empty(M, Cin, device=cuda), torch.empty(M, Cin, device=cuda), torch.empty(Cin, device=cuda), torch.empty(Cin, device=cuda)
+        N.check(L.osi_bn_backward_relu_mask(N.ptr(dx_raw), N.ptr(mask), N.ptr(yv), N.ptr(st[0]), N.ptr(st[1]), N.ptr(gv), N.ptr(dyo), N.ptr(gm),
+                                            N.ptr(dg), N.ptr(db), M, Cin, N.ptr(ws), wsb, T.S()))
+        ref.append((dyo, gm, dg, db))
+    # fused
+    pb = L.osi_conv_dgrad_fused_workspace(ctypes.byref(d))
+    parts = torch.full((pb // 4,), float("nan"), device=cuda)
+    f = _Fusion(mask.data_ptr(), ys[0].data_ptr(), stats[0][0].data_ptr(), stats[0][1].data_ptr(),
+                ys[1].data_ptr() if two else None, stats[1][0].data_ptr() if two else None, stats[1][1].data_ptr() if two else None,
+                parts.data_ptr(), pb)
+    gbuf = torch.full((B, H, H, Cin), float("nan"), device=cuda)
+    P = ctypes.c_int()
+    N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(gbuf), N.ptr(addend), ctypes.byref(f), 0, ctypes.byref(P), T.S()))
+    assert torch.equal(gbuf.view(M, Cin), ref[0][1]), "masked gradient must match bit for bit"
+    pm = parts.view(3, -1)[:, :P.value * Cin].reshape(3, P.value, Cin) if False else None
+    for j, (yv, gv, st) in enumerate(zip(ys, ga, stats)):
+        dyo, dg, db = torch.empty(M, Cin, device=cuda), torch.empty(Cin, device=cuda), torch.empty(Cin, device=cuda)
+        psum_g = parts.data_ptr()
+        psum_gx = parts.data_ptr() + 4 * (1 + j) * P.value * Cin
+        N.check(L.osi_bn_backward_fused(N.ptr(gbuf), N.ptr(yv), N.ptr(st[0]), N.ptr(st[1]), N.ptr(gv), psum_g, psum_gx, P.value, N.ptr(dyo),
+                                        N.ptr(dg), N.ptr(db), M, Cin, N.ptr(ws), wsb, T.S()))
+        rdy, _, rdg, rdb = ref[j]
+        scale = float(rdy.abs().max()) + 1e-30
+        assert float((dyo - rdy).abs().max()) <= 2e-5 * scale, f"dy consumer {j}"
+        assert float((dg - rdg).abs().max()) <= 2e-5 * (float(rdg.abs().max()) + 1e-30), f"dgamma consumer {j}"
+        assert float((db - rdb).abs().max()) <= 2e-5 * (float(rdb.abs().max()) + 1e-30), f"dbeta consumer {j}"
