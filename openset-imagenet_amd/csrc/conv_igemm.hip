@@ -185,6 +185,8 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
     const int T = p.Ktot / BK;
     int r = 0, s = 0, c0 = 0;  // current tap / channel offset (non-stem)
     f32x4 ra[AR], rb[BR];
+    unsigned ra_ok = 0;  // zero-padding flags of ra: applied when the registers are written to LDS, AFTER the MFMAs of the
+                         // current stage, so the compiler waits for the loads there and not before the MFMA block
 
     auto gload = [&](int t) {
 #pragma unroll
@@ -201,8 +203,8 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
             }
             ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             int off = ok ? a_base[i] + (hi * p.W + wi) * p.Cin + coff : 0;
-            f32x4 v = ld4(p.x + off);
-            ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[i] = ld4(p.x + off);
+            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) rb[i] = ld4(wrow + (size_t)(32 * i) * p.Ktot + t * BK);
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         float* sA = smem + buf * STAGE;
         float* sB = sA + BM * LDR;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = (ra_ok >> i) & 1 ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(sB + (lr + 32 * i) * LDR + kq * 4) = rb[i];
     };
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
     const int T = nR * nS * KC;
     int jr = 0, js = 0, c0 = 0;
     f32x4 ra[AR], rbv[BRN];
+    unsigned ra_ok = 0;  // see k_conv_fwd: the zero-fill select is deferred to the LDS store
     const int bk_row = tid / BV, bk_col = (tid % BV) * 4;
 
     auto gload = [&]() {
@@ -376,8 +380,8 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
             int ho = a_hb[i] - jr, wo = a_wb[i] - js;
             bool ok = a_ok[i] && (p.unit || ((unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo));
             int off = ok ? a_base[i] + (ho * p.Wo + wo) * p.Cout + c0 + kq * 4 : 0;
-            f32x4 v = ld4(p.x + off);
-            ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[i] = ld4(p.x + off);
+            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
         }
         // weight tile: rows k = cout c0..c0+31, cols = cin n0..n0+BN-1 at tap (r,s)
 #pragma unroll
@@ -394,7 +398,8 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         float* sA = smem + buf * STAGE;
         float* sB = sA + BM * LDR;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = (ra_ok >> i) & 1 ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (bk_row + BRP * i) * LDC + bk_col) = rbv[i];
     };
@@ -546,6 +551,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
     const int a_row = tid / AV, a_col = (tid % AV) * 4;
     const int b_row = tid / BV, b_col = (tid % BV) * 4;
     f32x4 ra[ARN], rbv[BRN];
+    unsigned ra_ok = 0, rb_ok = 0;  // see k_conv_fwd: the zero-fill selects are deferred to the LDS store
 
     auto gload = [&](int t) {
         const int kb = kbeg + t * BK;
@@ -553,8 +559,8 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
         for (int i = 0; i < ARN; ++i) {
             int m = kb + a_row + ARP * i;
             bool ok = m < kend;
-            f32x4 v = ld4(p.w + (size_t)(ok ? m : 0) * p.Cout + n0 + a_col);
-            ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[i] = ld4(p.w + (size_t)(ok ? m : 0) * p.Cout + n0 + a_col);
+            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
         }
 #pragma unroll
         for (int i = 0; i < BRN; ++i) {
@@ -574,17 +580,19 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
             int hi = (int)ho * p.stride - p.pad + rr, wi = (int)wo * p.stride - p.pad + ss;
             ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             int off = ok ? (((int)b * p.H + hi) * p.W + wi) * p.Cin + coff : 0;
-            f32x4 v = ld4(p.x + off);
-            rbv[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            rbv[i] = ld4(p.x + off);
+            rb_ok = ok ? (rb_ok | (1u << i)) : (rb_ok & ~(1u << i));
         }
     };
     auto sstore = [&](int buf) {
         float* sA = smem + buf * STAGE;
         float* sB = sA + BK * LDA;
 #pragma unroll
-        for (int i = 0; i < ARN; ++i) *reinterpret_cast<f32x4*>(sA + (a_row + ARP * i) * LDA + a_col) = ra[i];
+        for (int i = 0; i < ARN; ++i)
+            *reinterpret_cast<f32x4*>(sA + (a_row + ARP * i) * LDA + a_col) = (ra_ok >> i) & 1 ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (b_row + BRP * i) * LDB + b_col) = rbv[i];
+        for (int i = 0; i < BRN; ++i)
+            *reinterpret_cast<f32x4*>(sB + (b_row + BRP * i) * LDB + b_col) = (rb_ok >> i) & 1 ? rbv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
     if (T > 0) {
@@ -924,7 +932,9 @@ int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, floa
     p.x = x; p.w = dy; p.y = w.splits > 1 ? (float*)ws : dw;
     p.kchunk = w.kchunk; p.slab_stride = n;
     int e;
-    static const int nst = wgrad_env("OSI_WGRAD_NST", 1);
+    // Double-buffered by default: alone, the single-buffered form is ~3 % faster, but the weight gradients run beside the main
+    // stream (executor side stream) and the form with fewer resident workgroups per CU disturbs it less (measured on the full step).
+    static const int nst = wgrad_env("OSI_WGRAD_NST", 2);
     if (stem) e = launch_wgrad<1, 1, true>(p, w.splits, st);
     else if (w.wm == 2 && w.wn == 2) e = nst == 1 ? launch_wgrad<2, 2, false, 1>(p, w.splits, st) : launch_wgrad<2, 2, false>(p, w.splits, st);
     else if (w.wm == 2) e = nst == 1 ? launch_wgrad<2, 1, false, 1>(p, w.splits, st) : launch_wgrad<2, 1, false>(p, w.splits, st);

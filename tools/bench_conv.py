@@ -46,7 +46,7 @@ for Cin, Cout, k, s, H, cnt in SHAPES:
     res = {}
     for name, cdim in (("fwd", Cout), ("dgrad", Cin)):
         r = []
-        for tile in (0, 5, 6, 7, 8):
+        for tile in (0, 1, 3, 4, 5, 6, 7, 8):
             if tile in (1, 3, 6, 7) and cdim % 128:
                 r.append(0.0); continue
             if name == "fwd":
