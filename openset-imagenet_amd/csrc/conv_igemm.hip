@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         uint32_t rem = mm - b * p.dHoWo.d;
         uint32_t ho = fdiv(rem, p.dWo);
         uint32_t wo = rem - ho * p.dWo.d;
-        a_base[i] = (int)b * p.H * p.W * p.Cin;
+        a_base[i] = (!STEM && p.unit) ? (int)mm * p.Cin : (int)b * p.H * p.W * p.Cin;
         a_h0[i] = (int)ho * p.stride - p.pad;
         a_w0[i] = (int)wo * p.stride - p.pad;
     }
@@ -193,6 +193,11 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         for (int i = 0; i < AR; ++i) {
             int hi, wi, coff;
             bool ok = a_ok[i];
+            if (!STEM && p.unit) {   // 1x1 stride-1: the im2col row of output pixel m is input row m, no halo, no bounds
+                ra[i] = ld4(p.x + a_base[i] + t * BK + kq * 4);
+                ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
+                continue;
+            }
             if (STEM) {
                 int tap = t * 8 + kq;  // Cin = 4: one tap per float4
                 int rr = tap / 7, ss = tap - rr * 7;
@@ -567,6 +572,11 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
             int m = kb + b_row + BRP * i;
             bool ok = m < kend;
             uint32_t mm = ok ? (uint32_t)m : 0u;
+            if (!STEM && p.unit) {   // 1x1 stride-1: pixel m of the output is pixel m of the input
+                rbv[i] = ld4(p.x + (size_t)mm * p.Cin + c0 + b_col);
+                rb_ok = ok ? (rb_ok | (1u << i)) : (rb_ok & ~(1u << i));
+                continue;
+            }
             uint32_t b = fdiv(mm, p.dHoWo);
             uint32_t rem = mm - b * p.dHoWo.d;
             uint32_t ho = fdiv(rem, p.dWo);
@@ -808,6 +818,7 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
     hipStream_t st = (hipStream_t)stream;
     ConvP p = make_p(d);
     p.x = x; p.w = w; p.y = y; p.accumulate = 0;
+    p.unit = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) ? 1 : 0;
     auto with_stats = [&](int bm) -> int {
         if (!pstats) return OSI_OK;
         const int mt = osi_cdiv(p.M, bm);
@@ -828,7 +839,9 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
         // shorter; only the 7x7-spatial layers with few column tiles prefer the wider 64x128 tile.
         // Single-buffered LDS (two barriers per K tile, but 7-8 resident workgroups per CU) beats the double-buffered form on
         // every shape: occupancy, not staging depth, is what hides the barrier and load latency of a 16-MFMA K step.
-        tile = d->Cout >= 512 ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
+        // 64x64 everywhere except the 7x7-spatial layers with few tiles, where the wider column tile halves the A re-reads
+        const long tiles64 = ((long)p.M + 63) / 64 * (d->Cout / 64);
+        tile = (tiles64 < 1024 && d->Cout % 128 == 0) ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
     }
     if (int e = with_stats(fwd_tile_rows(tile))) return e;
     switch (tile) {
@@ -930,6 +943,7 @@ int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, floa
     OSI_REQUIRE(n % 4 == 0);
     if (w.splits > 1) OSI_REQUIRE(ws && ws_bytes >= (size_t)w.splits * n * sizeof(float));
     p.x = x; p.w = dy; p.y = w.splits > 1 ? (float*)ws : dw;
+    p.unit = (!stem && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) ? 1 : 0;
     p.kchunk = w.kchunk; p.slab_stride = n;
     int e;
     // Double-buffered by default: alone, the single-buffered form is ~3 % faster, but the weight gradients run beside the main
