@@ -39,6 +39,7 @@ struct ConvP {
     int Ktot;         // R*S*Cin (row length of W)
     int MT, NT;       // tile counts
     int accumulate;   // epilogue adds into y
+    int x_bytes, w_bytes;  // sizes of p.x / p.w for the buffer descriptors
     FastDiv dHoWo, dWo;  // fwd/wgrad: divide by Ho*Wo, Wo
     FastDiv cHW[4], cW[4];  // dgrad: Hc*Wc and Wc of each parity class grid (stride <= 2)
     int unit;             // dgrad: 1x1 stride-1 conv -> the im2col row of pixel m is row m of dY
@@ -59,6 +60,16 @@ struct ConvP {
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// Buffer (SRSRC) loads: 32-bit byte offsets, and the hardware range check returns zeros for an offset >= num_records — the
+// im2col zero padding costs one select on the OFFSET (sentinel OOB) instead of four on the data plus validity bookkeeping.
+constexpr uint32_t OOB = 0x80000000u;   // every tensor here is < 2 GiB (desc_ok)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
 
 // XCD-aware tile mapping: workgroups b and b+8 share an XCD (and its L2). All NT column tiles of one row
 // tile are placed on one XCD in consecutive dispatch slots, so the im2col rows are fetched from HBM once.
@@ -156,9 +167,13 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
     const int m0 = mt * BM, n0 = nt * BN;
     const int kq = tid & 7, lr = tid >> 3;  // float4 slot inside a 32-float row, row inside a 32-row pass
 
-    // per-thread im2col rows
-    int a_base[AR], a_h0[AR], a_w0[AR];
+    // per-thread im2col rows. Generic path: a_base = offset of tap (0,0) of the row's window (may lie outside the tensor, only
+    // dereferenced when the tap is valid) and a_taps = bit (r*S+s) set when that tap is inside the image, so a load costs one add
+    // and one bit test instead of re-deriving (hi, wi) and four comparisons.
+    int a_base[AR], a_h0[AR], a_w0[AR];   // a_base: BYTE offset (incl. this thread's float4 slot), may be negative for halo rows
+    unsigned a_taps[AR];
     bool a_ok[AR];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.w, p.w_bytes);
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int m = m0 + lr + 32 * i;
@@ -168,11 +183,22 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         uint32_t rem = mm - b * p.dHoWo.d;
         uint32_t ho = fdiv(rem, p.dWo);
         uint32_t wo = rem - ho * p.dWo.d;
-        a_base[i] = (!STEM && p.unit) ? (int)mm * p.Cin : (int)b * p.H * p.W * p.Cin;
         a_h0[i] = (int)ho * p.stride - p.pad;
         a_w0[i] = (int)wo * p.stride - p.pad;
+        a_taps[i] = 0;
+        if (STEM) {
+            a_base[i] = (int)b * p.H * p.W * p.Cin * 4;
+        } else if (p.unit) {
+            a_base[i] = a_ok[i] ? ((int)mm * p.Cin + kq * 4) * 4 : (int)OOB;
+        } else {
+            a_base[i] = (((int)b * p.H * p.W + a_h0[i] * p.W + a_w0[i]) * p.Cin + kq * 4) * 4;
+            for (int rr = 0; rr < p.R; ++rr)
+                for (int ss = 0; ss < p.S; ++ss)
+                    if ((unsigned)(a_h0[i] + rr) < (unsigned)p.H && (unsigned)(a_w0[i] + ss) < (unsigned)p.W) a_taps[i] |= 1u << (rr * p.S + ss);
+            if (!a_ok[i]) a_taps[i] = 0;
+        }
     }
-    const float* wrow = p.w + (size_t)(n0 + lr) * p.Ktot + kq * 4;
+    const uint32_t w_voff = ((uint32_t)(n0 + lr) * p.Ktot + kq * 4) * 4;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -185,34 +211,25 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
     const int T = p.Ktot / BK;
     int r = 0, s = 0, c0 = 0;  // current tap / channel offset (non-stem)
     f32x4 ra[AR], rb[BR];
-    unsigned ra_ok = 0;  // zero-padding flags of ra: applied when the registers are written to LDS, AFTER the MFMAs of the
-                         // current stage, so the compiler waits for the loads there and not before the MFMA block
 
     auto gload = [&](int t) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            int hi, wi, coff;
-            bool ok = a_ok[i];
-            if (!STEM && p.unit) {   // 1x1 stride-1: the im2col row of output pixel m is input row m, no halo, no bounds
-                ra[i] = ld4(p.x + a_base[i] + t * BK + kq * 4);
-                ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
-                continue;
-            }
             if (STEM) {
                 int tap = t * 8 + kq;  // Cin = 4: one tap per float4
                 int rr = tap / 7, ss = tap - rr * 7;
-                hi = a_h0[i] + rr; wi = a_w0[i] + ss; coff = 0;
-                ok = ok && tap < 49;
+                int hi = a_h0[i] + rr, wi = a_w0[i] + ss;
+                bool ok = a_ok[i] && tap < 49 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                ra[i] = bld4(rx, ok ? (uint32_t)(a_base[i] + (hi * p.W + wi) * 16) : OOB, 0);
+            } else if (p.unit) {   // 1x1 stride-1: row m of the input, K offset in the scalar operand; no VALU at all
+                ra[i] = bld4(rx, (uint32_t)a_base[i], (uint32_t)(t * BK * 4));
             } else {
-                hi = a_h0[i] + r; wi = a_w0[i] + s; coff = c0 + kq * 4;
+                const bool ok = (a_taps[i] >> (r * p.S + s)) & 1;
+                ra[i] = bld4(rx, ok ? (uint32_t)(a_base[i] + ((r * p.W + s) * p.Cin + c0) * 4) : OOB, 0);
             }
-            ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            int off = ok ? a_base[i] + (hi * p.W + wi) * p.Cin + coff : 0;
-            ra[i] = ld4(p.x + off);
-            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = ld4(wrow + (size_t)(32 * i) * p.Ktot + t * BK);
+        for (int i = 0; i < BR; ++i) rb[i] = bld4(rw, w_voff + (uint32_t)(32 * i) * p.Ktot * 4, (uint32_t)(t * BK * 4));
     };
     auto advance = [&]() {
         if (!STEM) {
@@ -224,8 +241,7 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         float* sA = smem + buf * STAGE;
         float* sB = sA + BM * LDR;
 #pragma unroll
-        for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = (ra_ok >> i) & 1 ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
 #pragma unroll
         for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(sB + (lr + 32 * i) * LDR + kq * 4) = rb[i];
     };
@@ -343,22 +359,30 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
     const int nS = sb < p.S ? (p.S - sb + st - 1) / st : 0;
 
     const FastDiv dHW = p.cHW[cls], dW = p.cW[cls];
-    int a_base[AR], a_hb[AR], a_wb[AR];
+    // a_base = offset of the dY pixel reached through the class's first tap (jr = js = 0); a_taps = bit (jr*nS+js) set when
+    // tap (jr, js) lands inside dY: one add and one bit test per load (see k_conv_fwd)
+    int a_base[AR];
+    unsigned a_taps[AR];
     bool a_ok[AR];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.w, p.w_bytes);
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int m = m0 + lr + 32 * i;
         a_ok[i] = m < Mc;
         uint32_t mm = a_ok[i] ? (uint32_t)m : 0u;
-        if (p.unit) {  // dY row = pixel index, never out of bounds
-            a_base[i] = (int)mm * p.Cout; a_hb[i] = 0; a_wb[i] = 0;
+        if (p.unit) {  // dY row = pixel index, never out of bounds (invalid rows of the last tile: OOB sentinel -> zeros)
+            a_base[i] = a_ok[i] ? ((int)mm * p.Cout + kq * 4) * 4 : (int)OOB; a_taps[i] = a_ok[i] ? 1u : 0u;
         } else {
             uint32_t b = fdiv(mm, dHW);
             uint32_t rem = mm - b * dHW.d;
             uint32_t h2 = fdiv(rem, dW), w2 = rem - h2 * dW.d;
-            a_base[i] = (int)b * p.Ho * p.Wo * p.Cout;
-            a_hb[i] = (ph + st * (int)h2 + p.pad - rb) / st;
-            a_wb[i] = (pw + st * (int)w2 + p.pad - sb) / st;
+            const int hb = (ph + st * (int)h2 + p.pad - rb) / st, wb = (pw + st * (int)w2 + p.pad - sb) / st;
+            a_base[i] = ((((int)b * p.Ho + hb) * p.Wo + wb) * p.Cout + kq * 4) * 4;   // BYTE offset
+            a_taps[i] = 0;
+            for (int j = 0; j < nR; ++j)
+                for (int k = 0; k < nS; ++k)
+                    if ((unsigned)(hb - j) < (unsigned)p.Ho && (unsigned)(wb - k) < (unsigned)p.Wo) a_taps[i] |= 1u << (j * nS + k);
+            if (!a_ok[i]) a_taps[i] = 0;
         }
     }
     (void)Hc0; (void)Wc0;
@@ -375,25 +399,24 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
     const int T = nR * nS * KC;
     int jr = 0, js = 0, c0 = 0;
     f32x4 ra[AR], rbv[BRN];
-    unsigned ra_ok = 0;  // see k_conv_fwd: the zero-fill select is deferred to the LDS store
     const int bk_row = tid / BV, bk_col = (tid % BV) * 4;
 
     auto gload = [&]() {
         const int r = rb + st * jr, s = sb + st * js;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            int ho = a_hb[i] - jr, wo = a_wb[i] - js;
-            bool ok = a_ok[i] && (p.unit || ((unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo));
-            int off = ok ? a_base[i] + (ho * p.Wo + wo) * p.Cout + c0 + kq * 4 : 0;
-            ra[i] = ld4(p.x + off);
-            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
+            if (p.unit) {
+                ra[i] = bld4(rx, (uint32_t)a_base[i], (uint32_t)(c0 * 4));
+            } else {
+                const bool ok = (a_taps[i] >> (jr * nS + js)) & 1;
+                ra[i] = bld4(rx, ok ? (uint32_t)(a_base[i] + (c0 - (jr * p.Wo + js) * p.Cout) * 4) : OOB, 0);
+            }
         }
-        // weight tile: rows k = cout c0..c0+31, cols = cin n0..n0+BN-1 at tap (r,s)
+        // weight tile: rows k = cout c0..c0+31, cols = cin n0..n0+BN-1 at tap (r,s); the tap / cout part is wave-uniform
+        const uint32_t wsoff = (uint32_t)((c0 * p.Ktot + (r * p.S + s) * p.Cin) * 4);
 #pragma unroll
-        for (int i = 0; i < BRN; ++i) {
-            int kk = bk_row + BRP * i;
-            rbv[i] = ld4(p.w + (size_t)(c0 + kk) * p.Ktot + (r * p.S + s) * p.Cin + n0 + bk_col);
-        }
+        for (int i = 0; i < BRN; ++i)
+            rbv[i] = bld4(rw, (uint32_t)(((bk_row + BRP * i) * p.Ktot + n0 + bk_col) * 4), wsoff);
     };
     auto advance = [&]() {
         c0 += BK;
@@ -403,8 +426,7 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         float* sA = smem + buf * STAGE;
         float* sB = sA + BM * LDR;
 #pragma unroll
-        for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = (ra_ok >> i) & 1 ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
 #pragma unroll
         for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (bk_row + BRP * i) * LDC + bk_col) = rbv[i];
     };
@@ -556,27 +578,24 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
     const int a_row = tid / AV, a_col = (tid % AV) * 4;
     const int b_row = tid / BV, b_col = (tid % BV) * 4;
     f32x4 ra[ARN], rbv[BRN];
-    unsigned ra_ok = 0, rb_ok = 0;  // see k_conv_fwd: the zero-fill selects are deferred to the LDS store
 
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rdy = make_rsrc(p.w, p.w_bytes);
     auto gload = [&](int t) {
         const int kb = kbeg + t * BK;
 #pragma unroll
-        for (int i = 0; i < ARN; ++i) {
-            int m = kb + a_row + ARP * i;
-            bool ok = m < kend;
-            ra[i] = ld4(p.w + (size_t)(ok ? m : 0) * p.Cout + n0 + a_col);
-            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
+        for (int i = 0; i < ARN; ++i) {   // dY rows: pixel part in the scalar offset, zero rows past the split's end via OOB
+            const int m = kb + a_row + ARP * i;
+            ra[i] = bld4(rdy, m < kend ? (uint32_t)(((a_row + ARP * i) * p.Cout + n0 + a_col) * 4) : OOB, (uint32_t)kb * p.Cout * 4);
         }
 #pragma unroll
         for (int i = 0; i < BRN; ++i) {
-            int m = kb + b_row + BRP * i;
+            const int m = kb + b_row + BRP * i;
             bool ok = m < kend;
-            uint32_t mm = ok ? (uint32_t)m : 0u;
             if (!STEM && p.unit) {   // 1x1 stride-1: pixel m of the output is pixel m of the input
-                rbv[i] = ld4(p.x + (size_t)mm * p.Cin + c0 + b_col);
-                rb_ok = ok ? (rb_ok | (1u << i)) : (rb_ok & ~(1u << i));
+                rbv[i] = bld4(rx, ok ? (uint32_t)(((b_row + BRP * i) * p.Cin + c0 + b_col) * 4) : OOB, (uint32_t)kb * p.Cin * 4);
                 continue;
             }
+            uint32_t mm = ok ? (uint32_t)m : 0u;
             uint32_t b = fdiv(mm, p.dHoWo);
             uint32_t rem = mm - b * p.dHoWo.d;
             uint32_t ho = fdiv(rem, p.dWo);
@@ -589,20 +608,16 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
             }
             int hi = (int)ho * p.stride - p.pad + rr, wi = (int)wo * p.stride - p.pad + ss;
             ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            int off = ok ? (((int)b * p.H + hi) * p.W + wi) * p.Cin + coff : 0;
-            rbv[i] = ld4(p.x + off);
-            rb_ok = ok ? (rb_ok | (1u << i)) : (rb_ok & ~(1u << i));
+            rbv[i] = bld4(rx, ok ? (uint32_t)(((((int)b * p.H + hi) * p.W + wi) * p.Cin + coff) * 4) : OOB, 0);
         }
     };
     auto sstore = [&](int buf) {
         float* sA = smem + buf * STAGE;
         float* sB = sA + BK * LDA;
 #pragma unroll
-        for (int i = 0; i < ARN; ++i)
-            *reinterpret_cast<f32x4*>(sA + (a_row + ARP * i) * LDA + a_col) = (ra_ok >> i) & 1 ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < ARN; ++i) *reinterpret_cast<f32x4*>(sA + (a_row + ARP * i) * LDA + a_col) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BRN; ++i)
-            *reinterpret_cast<f32x4*>(sB + (b_row + BRP * i) * LDB + b_col) = (rb_ok >> i) & 1 ? rbv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (b_row + BRP * i) * LDB + b_col) = rbv[i];
     };
 
     if (T > 0) {
@@ -692,9 +707,10 @@ static bool desc_ok(const osi_conv_desc* d) {
     if (d->Ho != (d->H + 2 * d->pad - d->R) / d->stride + 1) return false;
     if (d->Wo != (d->W + 2 * d->pad - d->S) / d->stride + 1) return false;
     if (d->Ho <= 0 || d->Wo <= 0) return false;
-    // 31-bit element offsets
-    if ((long)d->B * d->H * d->W * d->Cin >= (1l << 31)) return false;
-    if ((long)d->B * d->Ho * d->Wo * d->Cout >= (1l << 31)) return false;
+    // tensors below 2 GiB: 31-bit byte offsets for the buffer descriptors (and the OOB sentinel 0x80000000 stays out of range)
+    if ((long)d->B * d->H * d->W * d->Cin >= (1l << 29)) return false;
+    if ((long)d->B * d->Ho * d->Wo * d->Cout >= (1l << 29)) return false;
+    if ((long)d->Cout * d->R * d->S * (d->Cin < 4 ? 4 : d->Cin) >= (1l << 29)) return false;
     return true;
 }
 static bool is_stem(const osi_conv_desc* d) { return d->Cin == 4 && d->R == 7 && d->S == 7; }
@@ -819,6 +835,8 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
     ConvP p = make_p(d);
     p.x = x; p.w = w; p.y = y; p.accumulate = 0;
     p.unit = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) ? 1 : 0;
+    p.x_bytes = (int)((size_t)d->B * d->H * d->W * d->Cin * 4);
+    p.w_bytes = (int)((size_t)d->Cout * p.Ktot * 4);
     auto with_stats = [&](int bm) -> int {
         if (!pstats) return OSI_OK;
         const int mt = osi_cdiv(p.M, bm);
@@ -889,6 +907,8 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     hipStream_t st = (hipStream_t)stream;
     ConvP p = make_p(d);
     p.x = dy; p.w = w; p.y = dx; p.addend = addend;
+    p.x_bytes = (int)((size_t)d->B * d->Ho * d->Wo * d->Cout * 4);
+    p.w_bytes = (int)((size_t)d->Cout * p.Ktot * 4);
     if (tile == OSI_TILE_AUTO)  // measured (see osi_conv_fwd): 64 rows x the widest column tile the input channels allow
         tile = d->Cin % 128 == 0 ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
     if (f) {
@@ -944,6 +964,8 @@ int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, floa
     if (w.splits > 1) OSI_REQUIRE(ws && ws_bytes >= (size_t)w.splits * n * sizeof(float));
     p.x = x; p.w = dy; p.y = w.splits > 1 ? (float*)ws : dw;
     p.unit = (!stem && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) ? 1 : 0;
+    p.x_bytes = (int)((size_t)d->B * d->H * d->W * d->Cin * 4);
+    p.w_bytes = (int)((size_t)d->B * d->Ho * d->Wo * d->Cout * 4);
     p.kchunk = w.kchunk; p.slab_stride = n;
     int e;
     // Double-buffered by default: alone, the single-buffered form is ~3 % faster, but the weight gradients run beside the main
