@@ -101,7 +101,14 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumentation of the executor")
+    ap.add_argument("--force-dp", action="store_true", help="dev: with one rank, still run the data-parallel step (staged backward + "
+                    "RCCL bucket all-reduce on a world-1 communicator) to price the N>1 code path on a one-GPU box")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON); anything libraries print on fd 1 (RCCL's version banner, for one) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,8 +120,10 @@ def main():
     from openset_imagenet.dp import DistributedDataParallel
     N.lib()  # fail loudly if the HIP library is missing
     dev = tools.set_device_gpu(local)
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     wl = dict(WORKLOADS[args.workload])
@@ -123,7 +132,9 @@ def main():
     B, C = wl["B"], wl["C"]
     torch.manual_seed(42)
     model = tools.device(ResNet50(C, C, False))
-    net = DistributedDataParallel(model) if world > 1 else model
+    net = DistributedDataParallel(model) if use_dp else model
+    if args.force_dp and world == 1:
+        net.sync.world = 2   # AVG over one rank is the identity; the collectives are still enqueued
     opt = optim.Adam(model.parameters(), lr=1e-3)
     images, labels = synthetic_batch(B, C, wl["p_neg"], wl["loss"], dev, 42 + rank)
     if wl["loss"] == "garbage":
@@ -222,8 +233,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, wl["p_neg"])
             out["parity"] = parity
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dp:
         dist.destroy_process_group()
 
 

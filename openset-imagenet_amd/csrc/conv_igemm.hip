@@ -56,6 +56,7 @@ struct ConvP {
     int eP;
     // wgrad only
     int kchunk;       // pixels per split
+    int wtbl;         // generic loader: rolling table of input byte offsets in LDS instead of per-row divisions
     size_t slab_stride;
 };
 
@@ -580,6 +581,29 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
     f32x4 ra[ARN], rbv[BRN];
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rdy = make_rsrc(p.w, p.w_bytes);
+    // This workgroup works on ONE tap, so the input pixel of every output pixel of its split is known up front: resolve the
+    // (image, row, col) divisions and the padding test for a window of TW K-tiles into LDS (4 KiB, rebuilt every TW tiles);
+    // the loader then costs one ds_read + one add per row.
+    constexpr int TW = 32;
+    uint32_t* tbl = reinterpret_cast<uint32_t*>(smem + NST * STAGE);
+    const bool use_tbl = !STEM && p.wtbl;
+    auto build_tbl = [&](int t0) {
+        for (int i = tid; i < TW * BK; i += 256) {
+            const int m = kbeg + t0 * BK + i;
+            uint32_t off = OOB;
+            if (m < kend) {
+                uint32_t b = fdiv((uint32_t)m, p.dHoWo);
+                uint32_t rem = (uint32_t)m - b * p.dHoWo.d;
+                uint32_t ho = fdiv(rem, p.dWo);
+                uint32_t wo = rem - ho * p.dWo.d;
+                int hi = (int)ho * p.stride - p.pad + r, wi = (int)wo * p.stride - p.pad + s;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    off = (uint32_t)((((int)b * p.H + hi) * p.W + wi) * p.Cin * 4);
+            }
+            tbl[i] = off;
+        }
+        __syncthreads();
+    };
     auto gload = [&](int t) {
         const int kb = kbeg + t * BK;
 #pragma unroll
@@ -593,6 +617,10 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
             bool ok = m < kend;
             if (!STEM && p.unit) {   // 1x1 stride-1: pixel m of the output is pixel m of the input
                 rbv[i] = bld4(rx, ok ? (uint32_t)(((b_row + BRP * i) * p.Cin + c0 + b_col) * 4) : OOB, (uint32_t)kb * p.Cin * 4);
+                continue;
+            }
+            if (use_tbl) {   // OOB + a column offset is still past the end of the tensor
+                rbv[i] = bld4(rx, tbl[(t % TW) * BK + b_row + BRP * i] + (uint32_t)((c0 + b_col) * 4), 0);
                 continue;
             }
             uint32_t mm = ok ? (uint32_t)m : 0u;
@@ -621,11 +649,14 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
     };
 
     if (T > 0) {
+        if (use_tbl) build_tbl(0);
         gload(0);
         sstore(0);
         __syncthreads();
         for (int t = 0; t < T; ++t) {
             const int buf = NST == 2 ? (t & 1) : 0;
+            // every wave passed the barrier that ended tile t-1, i.e. finished reading the window that ends with tile t
+            if (use_tbl && t + 1 < T && (t + 1) % TW == 0) build_tbl(t + 1);
             if (t + 1 < T) gload(t + 1);
             const float* sA = smem + buf * STAGE;
             mma_CC<WM, WN, LDA, LDB>(sA, sA + BK * LDA, wm * 32 * WM, wn * 32 * WN, lane, acc);
@@ -774,6 +805,8 @@ static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
     p.NT = STEM ? osi_cdiv(p.Ktot, BN) : p.R * p.S * (p.Cin / BN);
     size_t smem = 2 * (size_t)BK * (BM + 4 + BN + 4) * sizeof(float);
     smem = smem / 2 * NST;
+    p.wtbl = (!STEM && !p.unit) ? 1 : 0;
+    if (p.wtbl) smem += 32 * BK * sizeof(uint32_t);   // TW * BK offsets
     if (int e = set_smem(k_conv_wgrad<WM, WN, STEM, NST>, smem)) return e;
     hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST>), dim3(p.MT * p.NT, splits), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
@@ -792,7 +825,11 @@ static WgradPlan plan_wgrad(const osi_conv_desc* d) {
     const int Ktot = stem ? 224 : d->R * d->S * d->Cin;
     const long tiles = (long)(d->Cout / BMg) * (stem ? osi_cdiv(Ktot, BNg) : d->R * d->S * (d->Cin / BNg));
     const long M = (long)d->B * d->Ho * d->Wo;
-    long splits = (1024 + tiles - 1) / tiles;               // aim at ~4 workgroups per CU
+    // ~2 workgroups per CU. Alone, 4 per CU is ~10 % faster, but the weight gradients run on the executor's side stream next to
+    // the data-gradient chain: two 38 KiB workgroups leave half of each CU's LDS and wave slots to the critical path, and the
+    // whole step is 0.7 ms shorter (sweep 256..2048 in DESIGN.md). OSI_WGRAD_BLOCKS overrides (development).
+    static const int target = getenv("OSI_WGRAD_BLOCKS") ? atoi(getenv("OSI_WGRAD_BLOCKS")) : 512;
+    long splits = (target + tiles - 1) / tiles;
     long maxs = (M + 8 * BK - 1) / (8 * BK);                // at least 8 K tiles per split (amortises the 64 KiB slab tile)
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
@@ -909,8 +946,9 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     p.x = dy; p.w = w; p.y = dx; p.addend = addend;
     p.x_bytes = (int)((size_t)d->B * d->Ho * d->Wo * d->Cout * 4);
     p.w_bytes = (int)((size_t)d->Cout * p.Ktot * 4);
-    if (tile == OSI_TILE_AUTO)  // measured (see osi_conv_fwd): 64 rows x the widest column tile the input channels allow
-        tile = d->Cin % 128 == 0 ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
+    // Measured (profiles/conv_layers_r01.txt and the full step): with buffer loads the 64x64 single-buffered tile wins or ties
+    // on every ResNet-50 shape (the dgrad class went 12.1 -> 11.0 ms per step against the 64x128 rule used before).
+    if (tile == OSI_TILE_AUTO) tile = OSI_TILE_64x64_S1;
     if (f) {
         OSI_REQUIRE(f->relu_mask || !f->partials);
         p.ebits = (const unsigned long long*)f->relu_mask;
@@ -968,9 +1006,9 @@ int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, floa
     p.w_bytes = (int)((size_t)d->B * d->Ho * d->Wo * d->Cout * 4);
     p.kchunk = w.kchunk; p.slab_stride = n;
     int e;
-    // Double-buffered by default: alone, the single-buffered form is ~3 % faster, but the weight gradients run beside the main
-    // stream (executor side stream) and the form with fewer resident workgroups per CU disturbs it less (measured on the full step).
-    static const int nst = wgrad_env("OSI_WGRAD_NST", 2);
+    // Single-buffered LDS by default (as in fwd/dgrad: twice the resident workgroups beat staging depth): 11.4 -> 10.3 ms per step
+    // for the wgrad class and -0.45 ms on the overlapped step, measured with the side-stream schedule of the executor.
+    static const int nst = wgrad_env("OSI_WGRAD_NST", 1);
     if (stem) e = launch_wgrad<1, 1, true>(p, w.splits, st);
     else if (w.wm == 2 && w.wn == 2) e = nst == 1 ? launch_wgrad<2, 2, false, 1>(p, w.splits, st) : launch_wgrad<2, 2, false>(p, w.splits, st);
     else if (w.wm == 2) e = nst == 1 ? launch_wgrad<2, 1, false, 1>(p, w.splits, st) : launch_wgrad<2, 1, false>(p, w.splits, st);
