@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev tool, run ON the GPU box (through gpurun) from the repo root: collects the rocprofv3 evidence bench.py's roofline cites.
 #   1. --kernel-trace --stats of the default bench command (per-kernel durations)
-#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (HBM-side bytes), kernel-trace only
+#   2. --pmc FETCH_SIZE, --pmc WRITE_SIZE (HBM-side bytes) and --pmc MfmaUtil (matrix-pipe busy %) in separate passes, kernel-trace only
 # Outputs land under gpurun_out/; tools/summarize_profiles.py turns them into the files committed under profiles/.
 set -e
 ROOT=$(pwd)
@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/${1:-prof_final}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_$c.json" 2> "$OUT/$c.err"
 done
 echo done

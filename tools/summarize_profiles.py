@@ -39,6 +39,20 @@ def pmc_per_step(path):
     return {k: v / steps for k, v in tot.items()}, steps
 
 
+def mfma_util_per_class(path):
+    """Duration-weighted mean of rocprofv3's derived MfmaUtil (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMDs), in %)."""
+    num, den = defaultdict(float), defaultdict(float)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != "MfmaUtil":
+                continue
+            dur = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            k = klass(row["Kernel_Name"])
+            num[k] += float(row["Counter_Value"]) * dur
+            den[k] += dur
+    return {k: round(num[k] / den[k], 2) for k in num if den[k] > 0}
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
@@ -54,6 +68,15 @@ def main():
         out[k] = {"fetch_GB_raw": round(fetch.get(k, 0) * 1024 / 1e9, 3),
                   "fetch_GB_x2_wide_read_correction": round(2 * fetch.get(k, 0) * 1024 / 1e9, 3),
                   "write_GB": round(write.get(k, 0) * 1024 / 1e9, 3)}
+    mf = os.path.join(src, "MfmaUtil", "p_counter_collection.csv")
+    if os.path.isfile(mf):
+        util = mfma_util_per_class(mf)
+        with open(os.path.join(dst, f"{tag}_mfma_util.json"), "w") as f:
+            json.dump({"_note": "rocprofv3 --pmc MfmaUtil over `bench.py --steps 3 --warmup 1` (kernels serialised by the counter "
+                                "collection): duration-weighted mean per kernel class of 100 * SQ_VALU_MFMA_BUSY_CYCLES / "
+                                "(GRBM_GUI_ACTIVE * SIMDs) — share of the launch during which the matrix pipe of a SIMD is busy",
+                       "mfma_busy_percent": util}, f, indent=1)
+        print("MfmaUtil", util)
     with open(os.path.join(dst, f"{tag}_hbm_traffic_per_step.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
