@@ -260,7 +260,28 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         __syncthreads();
     }
 
+    bool stored = false;
+    if constexpr (WM == 1 && WN == 1) {
+        if (!p.accumulate) {
+            // 64x64 tile: transpose through LDS so each lane stores 16 bytes (4 consecutive channels of a pixel), see k_conv_dgrad
+            constexpr int LDT = BN + 4;
+            static_assert(BM * LDT <= STAGE, "transposed tile must fit the operand stage");
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) smem[(wm * 32 + acc_row(rr, lane)) * LDT + wn * 32 + (lane & 31)] = acc[0][0][rr];
+            __syncthreads();
+            const int c4 = tid & 15, rg = tid >> 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rl = rg + 16 * k, m = m0 + rl;
+                if (m < p.M)
+                    *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + c4 * 4) = *reinterpret_cast<const f32x4*>(smem + rl * LDT + c4 * 4);
+            }
+            __syncthreads();   // the statistics below reuse the LDS
+            stored = true;
+        }
+    }
     // epilogue: 32 lanes of a half-wave write 128 contiguous bytes of one output row
+    if (!stored)
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -445,6 +466,86 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
             if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
             __syncthreads();
         }
+    }
+
+    if constexpr (WM == 1 && WN == 1) {
+        // Vectorised epilogue of the 64x64 tile (the form the executor uses): the accumulators are transposed through LDS so
+        // that every lane owns 4 consecutive channels of a pixel — addend, activation(s) and output move as 16-byte accesses
+        // (a quarter of the memory instructions of the accumulator layout), the ReLU mask words of a float4 are 32 contiguous
+        // bytes, and the BatchNorm column sums start as float4 per lane.
+        constexpr int LDT = BN + 4;
+        static_assert(BM * LDT <= STAGE, "transposed tile must fit the operand stage");
+        float* tile = smem;   // the K loop ended with a barrier: LDS is free
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) tile[(wm * 32 + acc_row(rr, lane)) * LDT + wn * 32 + (lane & 31)] = acc[0][0][rr];
+        __syncthreads();
+        const int c4 = tid & 15, rg = tid >> 4;
+        const int col = n0 + c4 * 4;
+        f32x4 sg = {0, 0, 0, 0}, s0 = sg, s1 = sg, mu0 = sg, is0 = sg, mu1 = sg, is1 = sg;
+        if (FUSED && p.esum) {
+            mu0 = ld4(p.emean0 + col); is0 = ld4(p.einv0 + col);
+            if (p.ey1) { mu1 = ld4(p.emean1 + col); is1 = ld4(p.einv1 + col); }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rl = rg + 16 * k;
+            const int m = m0 + rl;
+            if (m >= Mc) continue;
+            uint32_t pix = (uint32_t)m;
+            if (st != 1) {
+                const uint32_t b = fdiv((uint32_t)m, dHW);
+                const uint32_t rem = (uint32_t)m - b * dHW.d;
+                const uint32_t h2 = fdiv(rem, dW), w2 = rem - h2 * dW.d;
+                pix = (b * p.H + (ph + st * h2)) * p.W + (pw + st * w2);
+            }
+            const uint32_t off = pix * p.Cin + col;
+            f32x4 v = *reinterpret_cast<const f32x4*>(tile + rl * LDT + c4 * 4);
+            if (p.addend) v += ld4(p.addend + off);   // may be the output buffer itself: read and written by the same lane
+            if (FUSED) {
+                if (p.ebits) {   // 1 bit / element: words (i4 >> 6) * 4 + component, bit i4 & 63 (bn.hip)
+                    const uint32_t i4 = off >> 2;
+                    const ulonglong2* wp = reinterpret_cast<const ulonglong2*>(p.ebits + (size_t)(i4 >> 6) * 4);
+                    const ulonglong2 w01 = wp[0], w23 = wp[1];
+                    const int bit = i4 & 63;
+                    v[0] = (w01.x >> bit) & 1 ? v[0] : 0.f; v[1] = (w01.y >> bit) & 1 ? v[1] : 0.f;
+                    v[2] = (w23.x >> bit) & 1 ? v[2] : 0.f; v[3] = (w23.y >> bit) & 1 ? v[3] : 0.f;
+                }
+                if (p.esum) {    // BatchNorm-backward partial sums of the consumer(s): sum g, sum g*xhat0 [, sum g*xhat1]
+                    sg += v;
+                    s0 += (v * (ld4(p.ey0 + off) - mu0)) * is0;
+                    if (p.ey1) s1 += (v * (ld4(p.ey1 + off) - mu1)) * is1;
+                }
+            }
+            *reinterpret_cast<f32x4*>(p.y + off) = v;
+        }
+        if (FUSED && p.esum) {
+            // rows of one channel quad: 4 lanes of the wave (lane bits 4, 5), then the 4 waves through LDS, in wave order
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sg[e] += __shfl_xor(sg[e], 16, 64); s0[e] += __shfl_xor(s0[e], 16, 64); s1[e] += __shfl_xor(s1[e], 16, 64);
+                sg[e] += __shfl_xor(sg[e], 32, 64); s0[e] += __shfl_xor(s0[e], 32, 64); s1[e] += __shfl_xor(s1[e], 32, 64);
+            }
+            __syncthreads();   // every lane is done reading the transposed tile
+            if (lane < 16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float* dst = smem + (wave * BN + c4 * 4 + e) * 3;
+                    dst[0] = sg[e]; dst[1] = s0[e]; dst[2] = s1[e];
+                }
+            }
+            __syncthreads();
+            if (tid < BN) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) { const float* s = smem + (wv * BN + tid) * 3; a0 += s[0]; a1 += s[1]; a2 += s[2]; }
+                const size_t prow = (size_t)(cls * p.MT + mt) * p.Cin + n0 + tid;
+                const size_t pstride = (size_t)p.eP * p.Cin;
+                p.esum[prow] = a0;
+                p.esum[pstride + prow] = a1;
+                if (p.ey1) p.esum[2 * pstride + prow] = a2;
+            }
+        }
+        return;
     }
 
     // epilogue. Element offsets fit 31 bits (desc_ok). Rows are handled four at a time so that the fused form (addend + mask +
