@@ -919,17 +919,22 @@ struct WgradPlan { int wm, wn, splits, kchunk; };
 static WgradPlan plan_wgrad(const osi_conv_desc* d) {
     WgradPlan w;
     const bool stem = is_stem(d);
-    static const int force64 = getenv("OSI_WGRAD_TILE") ? atoi(getenv("OSI_WGRAD_TILE")) == 64 : 0;
-    w.wm = (!force64 && d->Cout % 128 == 0) ? 2 : 1;
-    w.wn = (!force64 && !stem && d->Cin % 128 == 0) ? 2 : 1;
+    // 128-wide tiles wherever the channel counts allow (OSI_WGRAD_TILE=64 forces 64x64 for A/B runs). Measured with the footprint
+    // budget below: 64x64 everywhere is ~8 % faster ALONE (wgrad class 11.1 -> 10.2 ms/step) but 0.4 ms slower inside the
+    // overlapped step (36.7-37.0 vs 36.3 ms): six short-lived small workgroups per CU disturb the dgrad chain more than two big ones.
+    static const int big = getenv("OSI_WGRAD_TILE") ? atoi(getenv("OSI_WGRAD_TILE")) != 64 : 1;
+    w.wm = (big && d->Cout % 128 == 0) ? 2 : 1;
+    w.wn = (big && !stem && d->Cin % 128 == 0) ? 2 : 1;
     const int BMg = 64 * w.wm, BNg = 64 * w.wn;
     const int Ktot = stem ? 224 : d->R * d->S * d->Cin;
     const long tiles = (long)(d->Cout / BMg) * (stem ? osi_cdiv(Ktot, BNg) : d->R * d->S * (d->Cin / BNg));
     const long M = (long)d->B * d->Ho * d->Wo;
-    // ~2 workgroups per CU. Alone, 4 per CU is ~10 % faster, but the weight gradients run on the executor's side stream next to
-    // the data-gradient chain: two 38 KiB workgroups leave half of each CU's LDS and wave slots to the critical path, and the
-    // whole step is 0.7 ms shorter (sweep 256..2048 in DESIGN.md). OSI_WGRAD_BLOCKS overrides (development).
-    static const int target = getenv("OSI_WGRAD_BLOCKS") ? atoi(getenv("OSI_WGRAD_BLOCKS")) : 512;
+    // Footprint budget per launch in units of 64x64 workgroups (a 128x128 workgroup counts as four): 2048 = two 128x128 or eight
+    // 64x64 workgroups per CU. Alone, twice that is ~10 % faster, but the weight gradients run on the executor's side stream next
+    // to the data-gradient chain and must leave half of each CU's LDS, registers and wave slots to the critical path: the whole
+    // step is 0.7 ms shorter this way (sweep in DESIGN.md §3). OSI_WGRAD_BLOCKS overrides (development).
+    static const int target64 = getenv("OSI_WGRAD_BLOCKS") ? atoi(getenv("OSI_WGRAD_BLOCKS")) : 2048;
+    const int target = target64 / (w.wm * w.wn);
     long splits = (target + tiles - 1) / tiles;
     long maxs = (M + 8 * BK - 1) / (8 * BK);                // at least 8 K tiles per split (amortises the 64 KiB slab tile)
     if (splits > maxs) splits = maxs;
