@@ -138,8 +138,12 @@ def main():
     opt = optim.Adam(model.parameters(), lr=1e-3)
     images, labels = synthetic_batch(B, C, wl["p_neg"], wl["loss"], dev, 42 + rank)
     if wl["loss"] == "garbage":
-        from openset_imagenet.dataset import LabelTable  # class weights of the synthetic label histogram (dataset.py:77-86)
-        table = LabelTable(torch.where(labels.cpu() == C - 1, -1, labels.cpu()).numpy())
+        # class weights from a dataset-level label histogram (dataset.py:77-86), not from one batch: every known class present
+        # (as in the protocol CSVs), the negatives at the workload's share
+        import numpy as np
+        from openset_imagenet.dataset import LabelTable
+        known = np.repeat(np.arange(C - 1), 100)
+        table = LabelTable(np.concatenate([known, -np.ones(int(len(known) * wl["p_neg"] / (1 - wl["p_neg"])), dtype=np.int64)]))
         table.replace_negative_label()
         loss_fn = GarbageLoss(table.calculate_class_weights())
     else:
