@@ -119,12 +119,20 @@ def main():
     from openset_imagenet import ResNet50, EntropicOpensetLoss, GarbageLoss, optim, tools, _native as N
     from openset_imagenet.dp import DistributedDataParallel
     N.lib()  # fail loudly if the HIP library is missing
+    # dev rehearsal of N > 1 on a box with fewer GPUs than ranks: OSI_BENCH_BACKEND=gloo lets several ranks share a device
+    # (RCCL refuses that); the measured number is then meaningless, only the multi-rank control flow is exercised
+    backend = os.environ.get("OSI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(1, torch.cuda.device_count())
     dev = tools.set_device_gpu(local)
     use_dp = world > 1 or args.force_dp
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
