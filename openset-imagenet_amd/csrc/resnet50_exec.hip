@@ -66,7 +66,7 @@ struct osi_resnet50 {
     // stem
     int Hs, Ws, Hp, Wp;              // stem conv output, maxpool output
     size_t x4, wpack, gpack, a_pool, pool_idx, pooled, feat, logits_ws;
-    size_t bn_ws, bn_ws_bytes, wg_ws, wg_ws_bytes, dg_ws, dg_ws_bytes;
+    size_t bn_ws, bn_ws2, bn_ws_bytes, wg_ws, wg_ws_bytes, dg_ws, dg_ws_bytes;   // bn_ws2: BatchNorm scratch of the side-stream branch
     static constexpr int NSCR = 12;   // scratch activations-gradient buffers (each = largest activation)
     size_t scratch[NSCR], scratch_floats;
     size_t dfeat, dpooled;
@@ -250,7 +250,7 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
         if (wg > wgws) wgws = wg;
         if (!(c.d.Cin == 4 && c.d.R == 7)) { size_t dg = osi_conv_dgrad_fused_workspace(&c.d); if (dg > dgws) dgws = dg; }
     }
-    n->bn_ws_bytes = bnws; n->bn_ws = n->ws_alloc(bnws / 4 + 4);
+    n->bn_ws_bytes = bnws; n->bn_ws = n->ws_alloc(bnws / 4 + 4); n->bn_ws2 = n->ws_alloc(bnws / 4 + 4);
     n->wg_ws_bytes = wgws; n->wg_ws = n->ws_alloc(wgws / 4 + 4);
     n->dg_ws_bytes = dgws; n->dg_ws = n->ws_alloc(dgws / 4 + 4);
     n->scratch_floats = maxact;
@@ -317,15 +317,15 @@ int osi_resnet50_profile_read(osi_resnet50_t n, double* ms, int* count) {
 }
 
 static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buffers, float* ws, const float* x, const float* w,
-                       int training, hipStream_t st) {
+                       int training, hipStream_t st, size_t bn_ws_off) {
     Conv& c = n->convs[ci];
     BN& b = n->bns[c.bn];
     if (training) {
         // batch statistics come out of the conv epilogue (per row tile), only a tiny per-channel merge follows
         int P = 0, rows = 0;
-        OSI_TRY(osi_conv_fwd_bnstats(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, ws + n->bn_ws, n->bn_ws_bytes, &P, &rows, st));
+        OSI_TRY(osi_conv_fwd_bnstats(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
         n->mark(OSI_PROF_CONV_FWD, st);
-        OSI_TRY(osi_bn_finalize_stats(ws + n->bn_ws, n->bn_ws_bytes, P, rows, b.M, b.C, params + b.g_off, params + b.b_off, 1e-5f, 0.1f,
+        OSI_TRY(osi_bn_finalize_stats(ws + bn_ws_off, n->bn_ws_bytes, P, rows, b.M, b.C, params + b.g_off, params + b.b_off, 1e-5f, 0.1f,
                                       buffers + b.rm_off, buffers + b.rv_off, ws + b.mean, ws + b.invstd, ws + b.scale,
                                       ws + b.shift, st));
     } else {
@@ -345,13 +345,14 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     n->fwd_done = false;
+    if (training && n->overlap && !n->prof_on) OSI_TRY(n->ensure_side());
     n->mark(OSI_PROF_START, st);
     // stem
     OSI_TRY(osi_nchw3_to_nhwc4(image, ws + n->x4, n->B, n->H, n->W, st));
     Conv& c0 = n->convs[0];
     OSI_TRY(osi_stem_weight_pack(params + c0.w_off, ws + n->wpack, 64, st));
     n->mark(OSI_PROF_OTHER, st);
-    OSI_TRY(conv_bn_fwd(n, 0, params, buffers, ws, ws + n->x4, ws + n->wpack, training, st));
+    OSI_TRY(conv_bn_fwd(n, 0, params, buffers, ws, ws + n->x4, ws + n->wpack, training, st, n->bn_ws));
     BN& b0 = n->bns[c0.bn];
     OSI_TRY(osi_bn_apply_relu_mask(ws + c0.y, nullptr, ws + b0.scale, ws + b0.shift, ws + c0.a, ws + c0.mask, b0.M, 64, st));
     n->mark(OSI_PROF_BN_FWD, st);
@@ -362,26 +363,38 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
         const float* x = ws + k.x_in;
         const int cs[3] = {k.c1, k.c2, k.c3};
         const float* in = x;
+        const float* res = x;
+        // The projection shortcut (4 blocks) only depends on the block input: with overlap on it runs on the side stream beside
+        // the main branch (its own BatchNorm scratch), and is joined before the residual add.
+        bool forked = false;
+        if (k.ds >= 0) {
+            Conv& c = n->convs[k.ds];
+            BN& b = n->bns[c.bn];
+            float* xd = ws + n->scratch[0];
+            hipStream_t ds_st = st;
+            static const bool fork_fwd = !(getenv("OSI_FWD_FORK") && getenv("OSI_FWD_FORK")[0] == '0');   // dev A/B switch
+            if (fork_fwd && n->async_wgrad()) {
+                if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
+                if (hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+                ds_st = n->side; forked = true;
+            }
+            OSI_TRY(conv_bn_fwd(n, k.ds, params, buffers, ws, x, params + c.w_off, training, ds_st, forked ? n->bn_ws2 : n->bn_ws));
+            OSI_TRY(osi_bn_apply(ws + c.y, nullptr, ws + b.scale, ws + b.shift, xd, b.M, b.C, 0, ds_st));
+            n->mark(OSI_PROF_BN_FWD, ds_st);
+            if (forked && hipEventRecord(n->ev_join, n->side) != hipSuccess) return OSI_ERR_LAUNCH;
+            res = xd;
+        }
         for (int j = 0; j < 3; ++j) {
             Conv& c = n->convs[cs[j]];
             BN& b = n->bns[c.bn];
-            OSI_TRY(conv_bn_fwd(n, cs[j], params, buffers, ws, in, params + c.w_off, training, st));
+            OSI_TRY(conv_bn_fwd(n, cs[j], params, buffers, ws, in, params + c.w_off, training, st, n->bn_ws));
             if (j < 2) {
                 OSI_TRY(osi_bn_apply_relu_mask(ws + c.y, nullptr, ws + b.scale, ws + b.shift, ws + c.a, ws + c.mask, b.M, b.C, st));
                 n->mark(OSI_PROF_BN_FWD, st);
                 in = ws + c.a;
             }
         }
-        const float* res = x;
-        if (k.ds >= 0) {
-            Conv& c = n->convs[k.ds];
-            BN& b = n->bns[c.bn];
-            OSI_TRY(conv_bn_fwd(n, k.ds, params, buffers, ws, x, params + c.w_off, training, st));
-            float* xd = ws + n->scratch[0];
-            OSI_TRY(osi_bn_apply(ws + c.y, nullptr, ws + b.scale, ws + b.shift, xd, b.M, b.C, 0, st));
-            n->mark(OSI_PROF_BN_FWD, st);
-            res = xd;
-        }
+        if (forked && hipStreamWaitEvent(st, n->ev_join, 0) != hipSuccess) return OSI_ERR_LAUNCH;
         Conv& c3 = n->convs[k.c3];
         BN& b3 = n->bns[c3.bn];
         OSI_TRY(osi_bn_apply_relu_mask(ws + c3.y, res, ws + b3.scale, ws + b3.shift, ws + c3.a, ws + c3.mask, b3.M, b3.C, st));
