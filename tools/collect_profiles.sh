@@ -9,6 +9,9 @@ OUT=$ROOT/gpurun_out/${1:-prof_final}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+# the same with the weight gradients kept on the main stream (no co-running kernels): per-kernel averages comparable with the
+# event-timed per-class figures of bench.py's roofline leg
+OSI_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d "$OUT/stats_serial" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof_serial.json" 2> "$OUT/stats_serial.err"
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_$c.json" 2> "$OUT/$c.err"
 done

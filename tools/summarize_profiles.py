@@ -58,6 +58,10 @@ def main():
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
     shutil.copy(os.path.join(src, "stats", "s_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+    ser = os.path.join(src, "stats_serial", "s_kernel_stats.csv")
+    if os.path.isfile(ser):
+        shutil.copy(ser, os.path.join(dst, f"{tag}_bench_kernel_stats_serialized.csv"))
+        shutil.copy(os.path.join(src, "bench_under_rocprof_serial.json"), os.path.join(dst, f"{tag}_bench_under_rocprof_serialized.json"))
     fetch, s1 = pmc_per_step(os.path.join(src, "FETCH_SIZE", "p_counter_collection.csv"))
     write, s2 = pmc_per_step(os.path.join(src, "WRITE_SIZE", "p_counter_collection.csv"))
     out = {"_note": "per training step (B=128, Protocol-2 workload), rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
