@@ -150,6 +150,18 @@ int osi_softmax(const float* logits, float* out, int B, int C, osi_stream_t stre
 int osi_confidence_accumulate(const float* logits, const long long* target, int B, int C, float offset, long long unknown_class,
                               int last_valid_class, double* acc4, osi_stream_t stream);
 
+/* Open-Set Classification Rate curve, util.calculate_oscr (util.py:90-122), on device-resident scores[N][C] (f32 or f64) and
+ * int64 labels. Outputs: taus[0 .. totals[0]) = the distinct target-class scores of the known samples in ascending order;
+ * for the totals[0] - 1 thresholds tau = taus[u] (the largest is dropped, util.py:114): ccr_count[u] = #{known, argmax == label,
+ * score[label] > tau}, fpr_count[u] = #{label == unk_label, max score > tau}; totals = {#distinct, #known, #unk_label}.
+ * The curve is ccr_count / totals[1], fpr_count / totals[2] in float64 (integer counts: bit-identical to the reference).
+ * taus / ccr_count / fpr_count hold N entries each, totals 3; ws: osi_oscr_workspace(N) bytes. */
+size_t osi_oscr_workspace(int N);
+int osi_oscr_f32(const float* scores, const long long* gt, int N, int C, long long unk_label, void* ws, size_t ws_bytes,
+                 float* taus, long long* ccr_count, long long* fpr_count, long long* totals, osi_stream_t stream);
+int osi_oscr_f64(const double* scores, const long long* gt, int N, int C, long long unk_label, void* ws, size_t ws_bytes,
+                 double* taus, long long* ccr_count, long long* fpr_count, long long* totals, osi_stream_t stream);
+
 /* ---- optimizer + arena utilities (train.py:356-359 construction, train.py:127,139 zero_grad/step) --- */
 int osi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                   double beta2, double eps, long long step, float grad_scale, osi_stream_t stream);

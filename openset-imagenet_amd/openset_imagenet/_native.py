@@ -66,6 +66,9 @@ _SIGS = {
     "osi_loss_fwd_bwd": (c_int, [c_int, P, P, c_int, c_int, c_float, c_longlong, P, P, c_int, c_float, c_float, P, P, P, P]),
     "osi_softmax": (c_int, [P, P, c_int, c_int, P]),
     "osi_confidence_accumulate": (c_int, [P, P, c_int, c_int, c_float, c_longlong, c_int, P, P]),
+    "osi_oscr_workspace": (c_size_t, [c_int]),
+    "osi_oscr_f32": (c_int, [P, P, c_int, c_int, c_longlong, P, c_size_t, P, P, P, P, P]),
+    "osi_oscr_f64": (c_int, [P, P, c_int, c_int, c_longlong, P, c_size_t, P, P, P, P, P]),
     "osi_adam_step": (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_longlong, c_float, P]),
     "osi_sgd_step": (c_int, [P, P, P, c_size_t, c_float, c_float, c_int, c_float, P]),
     "osi_fill_f32": (c_int, [P, c_size_t, c_float, P]),

@@ -131,3 +131,16 @@ def test_oracle_forward_reproduces_committed_vectors(golden_dir):
     logits, feats = R.forward({k: v.clone() for k, v in sd.items()}, x, True)
     assert np.allclose(logits.numpy(), V[f"{tag}.f32.logits"], atol=2e-5)
     assert np.allclose(logits.numpy(), V[f"{tag}.f64.logits"], atol=1e-4)
+
+
+def test_oscr_oracle_matches_reference(golden_dir):
+    """oracle/oscr_oracle.py (sort + binary search) against the vectors produced by the reference's own calculate_oscr loop
+    (util.py:90-122; tests/golden/make_golden_oscr.py): identical float64 arrays, nan for an absent sample class included."""
+    from oracle.oscr_oracle import calculate_oscr
+    G = np.load(os.path.join(golden_dir, "oscr_reference.npz"))
+    assert len(G["names"]) >= 10
+    for n in G["names"]:
+        ccr, fpr = calculate_oscr(G[f"{n}.gt"], G[f"{n}.scores"], int(G[f"{n}.unk"]))
+        assert ccr.dtype == np.float64 and ccr.shape == G[f"{n}.ccr"].shape, n
+        assert np.array_equal(ccr, G[f"{n}.ccr"], equal_nan=True), n
+        assert np.array_equal(fpr, G[f"{n}.fpr"], equal_nan=True), n
