@@ -125,6 +125,10 @@ int osi_bn_backward_fused(const float* g, const float* y, const float* mean, con
 
 /* ---- pooling / layout (ResNet.maxpool, ResNet.avgpool, flatten; image batch of train.py:128) --- */
 int osi_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int B, int H, int W, osi_stream_t stream);
+/* uint8 [B][H][W][3] -> fp32 [B][H][W][4] = value / 255 (ToTensor(), train.py:263), horizontally flipped where flip[b] != 0
+ * (RandomHorizontalFlip, train.py:262; flip may be NULL), 4th channel zero: the input pipeline's last mile on the device. */
+int osi_u8hwc3_to_nhwc4(const unsigned char* x_u8_nhwc, const unsigned char* flip, float* y_nhwc4, int B, int H, int W,
+                        osi_stream_t stream);
 /* idx: B*Ho*Wo*C bytes (argmax position 0..8 per element) */
 int osi_maxpool3x3s2_fwd(const float* x, float* y, void* idx, int B, int H, int W, int C, osi_stream_t stream);
 int osi_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, int B, int H, int W, int C, osi_stream_t stream);
@@ -197,7 +201,12 @@ int osi_resnet50_num_stages(osi_resnet50_t net);              /* backward stages
 /* floats [lo, hi) of the grads arena that are final once backward stage s has run */
 int osi_resnet50_stage_grad_range(osi_resnet50_t net, int s, size_t* lo, size_t* hi);
 
-/* image: [B][3][H][W] fp32 NCHW as the reference feeds it. training != 0: batch statistics + running-stat update. */
+/* Optional input staging from a uint8 [B][H][W][3] batch (osi_u8hwc3_to_nhwc4 into the executor's input buffer inside
+ * `workspace`); the next osi_resnet50_forward on that workspace passes image = NULL (OSI_ERR_STATE without a staged input). */
+int osi_resnet50_stage_input_u8(osi_resnet50_t net, const unsigned char* images_u8_nhwc, const unsigned char* flip,
+                                void* workspace, osi_stream_t stream);
+/* image: [B][3][H][W] fp32 NCHW as the reference feeds it (or NULL after osi_resnet50_stage_input_u8). training != 0: batch
+ * statistics + running-stat update. */
 int osi_resnet50_forward(osi_resnet50_t net, const float* params, float* buffers, long long* nbt, const float* image,
                          void* workspace, float* logits, float* features, int training, osi_stream_t stream);
 /* runs backward stages [stage_lo, stage_hi) given dJ/dlogits and (optionally, may be NULL) dJ/dfeatures */

@@ -100,9 +100,35 @@ __global__ __launch_bounds__(256) void k_avgpool_bwd(const f32x4* __restrict__ d
     dx[i] = dy[(size_t)b * C4 + c4] / (float)HW;
 }
 
+// uint8 [B][H][W][3] (a decoded, cropped RGB batch) -> fp32 [B][H][W][4]: ToTensor()'s value / 255 (a true division, like
+// torch's .div(255)), optional per-image horizontal flip, 4th channel zero. One pass replaces ToTensor + RandomHorizontalFlip of
+// the reference's transform (train.py:259-263) and the NCHW -> NHWC4 staging; the host link carries 1 byte per value, not 4.
+__global__ __launch_bounds__(256) void k_u8hwc3_to_nhwc4(const unsigned char* __restrict__ x, const unsigned char* __restrict__ flip,
+                                                        f32x4* __restrict__ y, int B, int H, int W) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)B * H * W, step = (size_t)gridDim.x * 256;
+    for (; i < n; i += step) {
+        const size_t row = i / W;                       // b * H + h
+        const int w = (int)(i - row * W);
+        const int b = (int)(row / H);
+        const int ws = (flip && flip[b]) ? W - 1 - w : w;
+        const unsigned char* s = x + (row * W + ws) * 3;
+        y[i] = f32x4{(float)s[0] / 255.0f, (float)s[1] / 255.0f, (float)s[2] / 255.0f, 0.f};
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int osi_u8hwc3_to_nhwc4(const unsigned char* x, const unsigned char* flip, float* y, int B, int H, int W, osi_stream_t stream) {
+    OSI_REQUIRE(x && y && B > 0 && H > 0 && W > 0);
+    size_t n = (size_t)B * H * W;
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_u8hwc3_to_nhwc4, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, flip, (f32x4*)y, B, H, W);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
 
 int osi_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, osi_stream_t stream) {
     OSI_REQUIRE(x && y && B > 0 && H > 0 && W > 0);

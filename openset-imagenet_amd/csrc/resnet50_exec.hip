@@ -133,6 +133,7 @@ struct osi_resnet50 {
     // Weight gradients run on a low-priority side stream: they are off the critical path of backward (nothing downstream
     // reads them before the optimizer) and fill the matrix pipes while the main stream is in HBM-bound BatchNorm kernels
     // or in the ragged last round of a dgrad launch. buf_ev[i] = last side-stream reader of scratch buffer i.
+    void* staged_ws = nullptr;   // workspace whose input buffer was filled by osi_resnet50_stage_input_u8 (consumed by one forward)
     bool overlap = true;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -338,17 +339,29 @@ static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buff
     return OSI_OK;
 }
 
+// Input staged from a uint8 [B][H][W][3] batch (+ optional per-image horizontal flip flags) straight into the executor's NHWC4
+// input buffer; the following osi_resnet50_forward call passes image = NULL.
+int osi_resnet50_stage_input_u8(osi_resnet50_t n, const unsigned char* images_u8_nhwc, const unsigned char* flip, void* workspace,
+                                osi_stream_t stream) {
+    OSI_REQUIRE(n && images_u8_nhwc && workspace);
+    OSI_TRY(osi_u8hwc3_to_nhwc4(images_u8_nhwc, flip, (float*)workspace + n->x4, n->B, n->H, n->W, stream));
+    n->staged_ws = workspace;
+    return OSI_OK;
+}
+
 int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, long long* nbt, const float* image,
                          void* workspace, float* logits, float* features, int training, osi_stream_t stream) {
-    OSI_REQUIRE(n && params && buffers && image && workspace && logits && features);
+    OSI_REQUIRE(n && params && buffers && workspace && logits && features);
     OSI_REQUIRE(!training || nbt);
+    if (!image && n->staged_ws != workspace) return OSI_ERR_STATE;   // image = NULL needs osi_resnet50_stage_input_u8 on this workspace
+    n->staged_ws = nullptr;
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     n->fwd_done = false;
     if (training && n->overlap && !n->prof_on) OSI_TRY(n->ensure_side());
     n->mark(OSI_PROF_START, st);
     // stem
-    OSI_TRY(osi_nchw3_to_nhwc4(image, ws + n->x4, n->B, n->H, n->W, st));
+    if (image) OSI_TRY(osi_nchw3_to_nhwc4(image, ws + n->x4, n->B, n->H, n->W, st));
     Conv& c0 = n->convs[0];
     OSI_TRY(osi_stem_weight_pack(params + c0.w_off, ws + n->wpack, 64, st));
     n->mark(OSI_PROF_OTHER, st);

@@ -55,15 +55,15 @@ class _BackboneFn(torch.autograd.Function):
     """Autograd node standing for the whole network: parameter gradients are written straight into the gradient arena."""
 
     @staticmethod
-    def forward(ctx, image, anchor, model):
+    def forward(ctx, image, anchor, model, flip):
         ctx.model = model
         ctx.set_materialize_grads(False)
-        return model._run_forward(image, True)
+        return model._run_forward(image, True, flip)
 
     @staticmethod
     def backward(ctx, dlogits, dfeatures):
         ctx.model._run_backward(dlogits, dfeatures)
-        return None, None, None
+        return None, None, None, None
 
 
 class ResNet50(nn.Module):
@@ -217,24 +217,40 @@ class ResNet50(nn.Module):
         return net
 
     def _check_image(self, image):
-        if not isinstance(image, torch.Tensor) or image.dim() != 4 or image.shape[1] != 3:
+        if isinstance(image, torch.Tensor) and image.dtype == torch.uint8:   # decoded RGB batch, staged on the device
+            if image.dim() != 4 or image.shape[3] != 3:
+                raise ValueError("a uint8 image batch must be [B, H, W, 3] (decoded RGB rows)")
+        elif not isinstance(image, torch.Tensor) or image.dim() != 4 or image.shape[1] != 3:
             raise ValueError("expected an image batch [B, 3, H, W]")
         if not image.is_cuda or not self._flat_params.is_cuda:
             raise RuntimeError("openset_imagenet (MI355X build) has no CPU path: move the model and the batch to the GPU "
                                "(set_device_gpu(index); device(model); device(images)).")
         if image.device != self._flat_params.device:
             raise RuntimeError("image batch and model live on different devices")
-        if image.dtype != torch.float32:
-            raise TypeError("image batch must be float32 (reference: ToTensor(), train.py:259-263)")
+        if image.dtype not in (torch.float32, torch.uint8):
+            raise TypeError("image batch must be float32 [B,3,H,W] (reference: ToTensor(), train.py:259-263) or uint8 [B,H,W,3]")
 
-    def _run_forward(self, image, want_grad):
-        B, _, H, W = image.shape
+    def _run_forward(self, image, want_grad, flip=None):
         image = image.contiguous()
+        staged = image.dtype == torch.uint8
+        if staged:
+            B, H, W, _ = image.shape
+        else:
+            B, _, H, W = image.shape
         net = self._net(B, H, W)
         logits = torch.empty(B, self._O, device=image.device)
         features = torch.empty(B, self._F, device=image.device)
+        if staged:   # ToTensor + horizontal flip + NHWC4 staging in one pass on the device (osi_u8hwc3_to_nhwc4)
+            if flip is not None:
+                flip = torch.as_tensor(flip).to(device=image.device, dtype=torch.uint8).contiguous()
+                if flip.numel() != B:
+                    raise ValueError("flip must hold one flag per image")
+            N.check(N.lib().osi_resnet50_stage_input_u8(net.h, N.ptr(image), N.ptr(flip), N.ptr(self._ws), N.stream_of(image)),
+                    "osi_resnet50_stage_input_u8")
+        elif flip is not None:
+            raise ValueError("flip flags are only meaningful with a uint8 [B,H,W,3] batch")
         N.check(N.lib().osi_resnet50_forward(net.h, N.ptr(self._flat_params), N.ptr(self._flat_buffers), N.ptr(self._nbt),
-                                             N.ptr(image), N.ptr(self._ws), N.ptr(logits), N.ptr(features),
+                                             None if staged else N.ptr(image), N.ptr(self._ws), N.ptr(logits), N.ptr(features),
                                              1 if self.training else 0, N.stream_of(image)), "osi_resnet50_forward")
         self._last = (net, image if want_grad else None)
         return logits, features
@@ -260,12 +276,16 @@ class ResNet50(nn.Module):
             sync.finish()
         self.bind_gradients()
 
-    def forward(self, image):
-        """Forward pass: returns (logits, deep features) like the reference (model.py:28-39)."""
+    def forward(self, image, flip=None):
+        """Forward pass: returns (logits, deep features) like the reference (model.py:28-39).
+
+        `image` is the reference's fp32 [B,3,H,W] batch in [0,1], or — the device-side input pipeline — a uint8 [B,H,W,3] batch
+        of decoded, cropped RGB rows with optional per-image horizontal-flip flags: ToTensor(), RandomHorizontalFlip and the
+        layout staging then happen in one pass on the GPU and the host link carries a quarter of the bytes."""
         self._check_image(image)
         if torch.is_grad_enabled() and self.training and self._plist[0].requires_grad:
-            return _BackboneFn.apply(image, self._anchor, self)
-        return self._run_forward(image, False)
+            return _BackboneFn.apply(image, self._anchor, self, flip)
+        return self._run_forward(image, False, flip)
 
 
 def net_shape(model, net):

@@ -181,9 +181,11 @@ def get_arrays(model, loader):
     return cat(t).astype(np.float32), cat(lg), cat(ft), cat(sc)
 
 
-def _image_loader(csv_file, imagenet_path, train, loss_type):
+def _image_loader(csv_file, imagenet_path, train, loss_type, uint8=True):
     """ImagenetDataset of the reference (dataset.py:10-54) with its transforms (train.py:259-268), PIL + torch only
-    (torchvision is not a dependency of this build). Host-side input pipeline: outside the GPU hot path."""
+    (torchvision is not a dependency of this build). Decode, Resize(256), crop and flip stay on the host workers; with
+    `uint8` (default) the sample is handed over as the uint8 [224,224,3] crop and ToTensor() runs on the GPU inside the model's
+    input staging (osi_u8hwc3_to_nhwc4): a quarter of the pinned-memory and host-link bytes, no fp32 work on the CPU."""
     import pandas as pd
     from PIL import Image
     from .dataset import LabelTable
@@ -217,7 +219,9 @@ def _image_loader(csv_file, imagenet_path, train, loss_type):
             img = img.crop((x0, y0, x0 + 224, y0 + 224))
             if train and random.random() < 0.5:
                 img = img.transpose(Image.FLIP_LEFT_RIGHT)
-            x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)  # ToTensor()
+            x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
+            if not uint8:
+                x = x.permute(2, 0, 1).float().div_(255.0)                                      # ToTensor() on the host
             return x, torch.as_tensor(int(label), dtype=torch.int64)
     return _DS()
 
@@ -265,8 +269,9 @@ def worker(cfg):
         val_file = pathlib.Path(cfg.data.val_file.format(cfg.protocol))
         if not (train_file.exists() and val_file.exists()):
             raise FileNotFoundError("train/validation file does not exist")
-        train_ds = _image_loader(train_file, cfg.data.imagenet_path, True, cfg.loss.type)
-        val_ds = _image_loader(val_file, cfg.data.imagenet_path, False, cfg.loss.type)
+        u8 = bool(getattr(cfg.data, "uint8", True))   # new key: False = fp32 CHW samples exactly as the reference's loader yields
+        train_ds = _image_loader(train_file, cfg.data.imagenet_path, True, cfg.loss.type, u8)
+        val_ds = _image_loader(val_file, cfg.data.imagenet_path, False, cfg.loss.type, u8)
         train_table = train_ds.table
     train_loader = torch.utils.data.DataLoader(train_ds, batch_size=cfg.batch_size, shuffle=True, num_workers=cfg.workers, pin_memory=True)
     val_loader = torch.utils.data.DataLoader(val_ds, batch_size=cfg.batch_size, num_workers=cfg.workers, pin_memory=True)
