@@ -69,8 +69,8 @@ def test_worker_on_jpeg_files(cuda, tmp_path, u8):
     rng = np.random.default_rng(0)
     img_dir = tmp_path / "imgs"
     img_dir.mkdir()
-    rows = {"train": [], "val": []}
-    for split, n in (("train", 10), ("val", 6)):
+    rows = {"train": [], "val": [], "test": []}
+    for split, n in (("train", 10), ("val", 6), ("test", 7)):
         for i in range(n):
             h, w = int(rng.integers(260, 340)), int(rng.integers(260, 400))      # odd sizes: Resize(256) really resizes
             Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(img_dir / f"{split}_{i}.jpg", quality=90)
@@ -79,14 +79,28 @@ def test_worker_on_jpeg_files(cuda, tmp_path, u8):
     proto.mkdir()
     (proto / "p2_train.csv").write_text("\n".join(rows["train"]) + "\n")
     (proto / "p2_val.csv").write_text("\n".join(rows["val"]) + "\n")
+    (proto / "p2_test.csv").write_text("\n".join(rows["test"]) + "\n")
     cfg = util.load_yaml(os.path.join(os.path.dirname(__file__), "..", "config", "train.yaml"))
     cfg.epochs, cfg.batch_size, cfg.workers, cfg.parallel, cfg.gpu, cfg.protocol = 1, 4, 0, True, 0, 2
-    cfg.loss.type = "entropic"
+    cfg.loss.type = cfg.name = "entropic"
     cfg.data.imagenet_path = str(img_dir)
     cfg.data.train_file, cfg.data.val_file = str(proto / "p{}_train.csv"), str(proto / "p{}_val.csv")
     cfg.data.uint8 = u8
     cfg.output_directory = str(tmp_path / "out")
     best = worker(cfg)
     assert np.isfinite(best)
-    ck = torch.load(tmp_path / "out" / "experiment_curr.pth", weights_only=False)
+    ck = torch.load(tmp_path / "out" / "entropic_curr.pth", weights_only=False)
     assert ck["epoch"] == 1 and ck["model_state_dict"]["logits.weight"].shape[0] == 3      # 3 known classes, -1 = negatives
+    if u8:   # the reference's evaluate.py surface on the checkpoint just written: arrays of both splits + the OSCR curve
+        from openset_imagenet.script import evaluate
+        from openset_imagenet.util import calculate_oscr
+        from oracle.oscr_oracle import calculate_oscr as oracle_oscr
+        files = evaluate.main(["entropic", "2", "-g", "0", "--imagenet-directory", str(img_dir), "--protocol-directory", str(proto),
+                               "--output-directory", str(tmp_path / "out"), "--batch-size", "4", "--workers", "0", "--oscr"])
+        for split, n in (("val", 6), ("test", 7)):
+            a = np.load(files[split])
+            assert a["gt"].shape == (n,) and a["logits"].shape == (n, 3) and a["features"].shape == (n, 3) and a["scores"].shape == (n, 3)
+            assert np.allclose(a["scores"].sum(1), 1, atol=1e-5)
+            ccr, fpr = calculate_oscr(a["gt"], a["scores"])
+            occr, ofpr = oracle_oscr(a["gt"], a["scores"])
+            assert np.array_equal(ccr, occr, equal_nan=True) and np.array_equal(fpr, ofpr, equal_nan=True)
