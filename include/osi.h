@@ -132,6 +132,16 @@ int osi_u8hwc3_to_nhwc4(const unsigned char* x_u8_nhwc, const unsigned char* fli
 /* idx: B*Ho*Wo*C bytes (argmax position 0..8 per element) */
 int osi_maxpool3x3s2_fwd(const float* x, float* y, void* idx, int B, int H, int W, int C, osi_stream_t stream);
 int osi_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, int B, int H, int W, int C, osi_stream_t stream);
+/* The ResNet stem tail (bn1 -> relu -> maxpool, torchvision ResNet.forward under model.py:37) as one pass each way:
+ *   fwd: pooled = maxpool3x3s2(relu(y*scale + shift)); the post-ReLU activation is never stored. idx bytes as above with bit 7 =
+ *        "window maximum > 0" (the ReLU gate of the pixel the gradient will return to).
+ *   bwd: gpool = dJ/dpooled -> dgamma, dbeta and dy = BatchNorm backward of the pool-scattered, ReLU-gated gradient, gathered on
+ *        the fly (no [B][H][W][C] gradient tensor). ws: osi_bn_backward_workspace(B*H*W, C) bytes. */
+int osi_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* pooled, void* idx, int B, int H, int W,
+                            int C, osi_stream_t stream);
+int osi_bn_relu_maxpool_bwd(const float* gpool, const void* idx, const float* y, const float* mean, const float* invstd,
+                            const float* gamma, float* dy, float* dgamma, float* dbeta, int B, int H, int W, int C, void* ws,
+                            size_t ws_bytes, osi_stream_t stream);
 int osi_avgpool_fwd(const float* x, float* y, int B, int HW, int C, osi_stream_t stream);
 int osi_avgpool_bwd(const float* dy, float* dx, int B, int HW, int C, osi_stream_t stream);
 

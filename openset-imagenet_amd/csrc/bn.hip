@@ -268,11 +268,44 @@ __device__ __forceinline__ f32x4 masked(f32x4 gv, const void* m, size_t i) {
     }
     return gv;
 }
+// MODE 3: the upstream gradient is not stored per element — it is gathered from the gradient of a 3x3 / stride 2 / pad 1 max
+// pool that followed BN + ReLU (the ResNet stem, osi_bn_relu_maxpool_fwd): pixel (h, w) receives the pooled gradient of every
+// window whose stored argmax is (h, w) and whose maximum was positive (bit 7 of the index byte = ReLU gate). Same window order
+// as k_maxpool_bwd, so the sums are the ones the unfused max-pool backward + ReLU mask would produce.
+struct PoolSrc {
+    const uint32_t* idx;   // [B][Ho][Wo][C/4] packed index bytes
+    FastDiv dW, dH;        // pixel -> (b, h, w)
+    int H, W, Ho, Wo;
+};
+__device__ __forceinline__ f32x4 pool_gather(const f32x4* __restrict__ gp, const PoolSrc& ps, uint32_t pix, int c4, int c4n) {
+    const uint32_t row = fdiv(pix, ps.dW);
+    const int w = (int)(pix - row * ps.dW.d);
+    const uint32_t b = fdiv(row, ps.dH);
+    const int h = (int)(row - b * ps.dH.d);
+    f32x4 acc = {0, 0, 0, 0};
+    for (int ho = h >> 1; ho <= (h + 1) >> 1; ++ho) {
+        if (ho >= ps.Ho) continue;
+        const int r = h - (ho * 2 - 1);
+        for (int wo = w >> 1; wo <= (w + 1) >> 1; ++wo) {
+            if (wo >= ps.Wo) continue;
+            const int s = w - (wo * 2 - 1);
+            const size_t o = ((size_t)(b * ps.Ho + ho) * ps.Wo + wo) * c4n + c4;
+            const uint32_t id = ps.idx[o];
+            const f32x4 g = gp[o];
+            const uint32_t me = (uint32_t)(r * 3 + s) | 0x80u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (((id >> (8 * k)) & 0xffu) == me) acc[k] += g[k];
+        }
+    }
+    return acc;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float* __restrict__ dA, const void* __restrict__ msk,
                                                       const float* __restrict__ y, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, int M, int C, int rows_per_blk,
-                                                      float* __restrict__ pdb, float* __restrict__ pdg) {
+                                                      float* __restrict__ pdb, float* __restrict__ pdg, PoolSrc ps) {
     __shared__ f32x4 red[2][NT];
     const int P = gridDim.x;
     const RowSplit sp = row_split(C);
@@ -294,14 +327,18 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_partial(const float* __restrict__
             int r = r0 + rl;
             for (; r + sp.RL < r1; r += 2 * sp.RL) {  // two independent rows in flight
                 const size_t i0 = (size_t)r * ld + c4, i1 = (size_t)(r + sp.RL) * ld + c4;
-                f32x4 g0 = pd[i0], g1 = pd[i1], y0 = py[i0], y1 = py[i1];
-                g0 = masked<MODE>(g0, msk, i0); g1 = masked<MODE>(g1, msk, i1);
+                f32x4 g0, g1, y0 = py[i0], y1 = py[i1];
+                if (MODE == 3) {
+                    g0 = pool_gather(pd, ps, (uint32_t)r, c4, (int)ld); g1 = pool_gather(pd, ps, (uint32_t)(r + sp.RL), c4, (int)ld);
+                } else {
+                    g0 = masked<MODE>(pd[i0], msk, i0); g1 = masked<MODE>(pd[i1], msk, i1);
+                }
                 sb += g0; sg += g0 * ((y0 - mu) * is);
                 sb2 += g1; sg2 += g1 * ((y1 - mu) * is);
             }
             for (; r < r1; r += sp.RL) {
                 const size_t i0 = (size_t)r * ld + c4;
-                f32x4 g0 = masked<MODE>(pd[i0], msk, i0);
+                f32x4 g0 = MODE == 3 ? pool_gather(pd, ps, (uint32_t)r, c4, (int)ld) : masked<MODE>(pd[i0], msk, i0);
                 sb += g0; sg += g0 * ((py[i0] - mu) * is);
             }
             sb += sb2; sg += sg2;
@@ -359,12 +396,12 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const f32x4* dA /* may alia
                                                     const f32x4* __restrict__ y, const f32x4* __restrict__ mean,
                                                     const f32x4* __restrict__ invstd, const f32x4* __restrict__ gamma,
                                                     const f32x4* __restrict__ c1, const f32x4* __restrict__ c2,
-                                                    f32x4* dy, f32x4* __restrict__ gout, size_t n4, int c4n) {
+                                                    f32x4* dy, f32x4* __restrict__ gout, size_t n4, int c4n, PoolSrc ps) {
     size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     const size_t step = (size_t)gridDim.x * NT;
     for (; i < n4; i += step) {
         int c4 = (int)(i % (size_t)c4n);
-        f32x4 gv = masked<MODE>(dA[i], msk, i);
+        f32x4 gv = MODE == 3 ? pool_gather(dA, ps, (uint32_t)(i / (size_t)c4n), c4, c4n) : masked<MODE>(dA[i], msk, i);
         f32x4 is = invstd[c4];
         f32x4 xh = (y[i] - mean[c4]) * is;
         f32x4 r = (gv - c1[c4] - xh * c2[c4]) * (gamma[c4] * is);
@@ -499,7 +536,7 @@ int osi_bn_apply_relu_mask(const float* y, const float* residual, const float* s
 
 static int bn_backward_impl(const float* dout, const void* msk, int mode, const float* y, const float* mean, const float* invstd,
                             const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
-                            size_t ws_bytes, hipStream_t st) {
+                            size_t ws_bytes, hipStream_t st, PoolSrc ps = PoolSrc{}) {
     OSI_REQUIRE(dout && y && mean && invstd && gamma && dy && dgamma && dbeta && ws);
     OSI_REQUIRE(M > 0 && C > 0 && C % 4 == 0);
     int P;
@@ -510,9 +547,10 @@ static int bn_backward_impl(const float* dout, const void* msk, int mode, const 
     float* pdg = pdb + (size_t)P * C;
     float* c1 = pdg + (size_t)P * C;
     float* c2 = c1 + C;
-    if (mode == 2) hipLaunchKernelGGL(k_bn_bwd_partial<2>, dim3(P), dim3(NT), 0, st, dout, msk, y, mean, invstd, M, C, rpb, pdb, pdg);
-    else if (mode == 1) hipLaunchKernelGGL(k_bn_bwd_partial<1>, dim3(P), dim3(NT), 0, st, dout, msk, y, mean, invstd, M, C, rpb, pdb, pdg);
-    else hipLaunchKernelGGL(k_bn_bwd_partial<0>, dim3(P), dim3(NT), 0, st, dout, msk, y, mean, invstd, M, C, rpb, pdb, pdg);
+    if (mode == 3) hipLaunchKernelGGL(k_bn_bwd_partial<3>, dim3(P), dim3(NT), 0, st, dout, msk, y, mean, invstd, M, C, rpb, pdb, pdg, ps);
+    else if (mode == 2) hipLaunchKernelGGL(k_bn_bwd_partial<2>, dim3(P), dim3(NT), 0, st, dout, msk, y, mean, invstd, M, C, rpb, pdb, pdg, ps);
+    else if (mode == 1) hipLaunchKernelGGL(k_bn_bwd_partial<1>, dim3(P), dim3(NT), 0, st, dout, msk, y, mean, invstd, M, C, rpb, pdb, pdg, ps);
+    else hipLaunchKernelGGL(k_bn_bwd_partial<0>, dim3(P), dim3(NT), 0, st, dout, msk, y, mean, invstd, M, C, rpb, pdb, pdg, ps);
     OSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, pdb, pdg, P, M, C, dgamma, dbeta, c1, c2);
     OSI_LAUNCH_CHECK();
@@ -522,8 +560,9 @@ static int bn_backward_impl(const float* dout, const void* msk, int mode, const 
     auto MU = (const f32x4*)mean; auto IS = (const f32x4*)invstd; auto G = (const f32x4*)gamma;
     auto C1 = (const f32x4*)c1; auto C2 = (const f32x4*)c2;
     auto DY = (f32x4*)dy; auto GO = (f32x4*)gmasked;
-#define OSI_BWD_APPLY(MODE_, EMIT_) hipLaunchKernelGGL((k_bn_bwd_apply<MODE_, EMIT_>), dim3(grid), dim3(NT), 0, st, D, msk, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n)
-    if (mode == 2) { if (gmasked) OSI_BWD_APPLY(2, true); else OSI_BWD_APPLY(2, false); }
+#define OSI_BWD_APPLY(MODE_, EMIT_) hipLaunchKernelGGL((k_bn_bwd_apply<MODE_, EMIT_>), dim3(grid), dim3(NT), 0, st, D, msk, Y, MU, IS, G, C1, C2, DY, GO, n4, c4n, ps)
+    if (mode == 3) OSI_BWD_APPLY(3, false);
+    else if (mode == 2) { if (gmasked) OSI_BWD_APPLY(2, true); else OSI_BWD_APPLY(2, false); }
     else if (mode == 1) { if (gmasked) OSI_BWD_APPLY(1, true); else OSI_BWD_APPLY(1, false); }
     else { if (gmasked) OSI_BWD_APPLY(0, true); else OSI_BWD_APPLY(0, false); }
 #undef OSI_BWD_APPLY
@@ -554,9 +593,21 @@ int osi_bn_backward_fused(const float* g, const float* y, const float* mean, con
     const size_t n4 = (size_t)M * C / 4;
     hipLaunchKernelGGL((k_bn_bwd_apply<0, false>), dim3(stream_grid(n4)), dim3(NT), 0, st, (const f32x4*)g, (const void*)nullptr,
                        (const f32x4*)y, (const f32x4*)mean, (const f32x4*)invstd, (const f32x4*)gamma, (const f32x4*)c1,
-                       (const f32x4*)c2, (f32x4*)dy, (f32x4*)nullptr, n4, C / 4);
+                       (const f32x4*)c2, (f32x4*)dy, (f32x4*)nullptr, n4, C / 4, PoolSrc{});
     OSI_LAUNCH_CHECK();
     return OSI_OK;
+}
+
+int osi_bn_relu_maxpool_bwd(const float* gpool, const void* idx, const float* y, const float* mean, const float* invstd,
+                            const float* gamma, float* dy, float* dgamma, float* dbeta, int B, int H, int W, int C, void* ws,
+                            size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(idx && B > 0 && H > 0 && W > 0 && (long)B * H * W < (1l << 31));
+    PoolSrc ps;
+    ps.idx = (const uint32_t*)idx;
+    ps.dW = make_fastdiv((uint32_t)W); ps.dH = make_fastdiv((uint32_t)H);
+    ps.H = H; ps.W = W; ps.Ho = (H + 2 - 3) / 2 + 1; ps.Wo = (W + 2 - 3) / 2 + 1;
+    return bn_backward_impl(gpool, nullptr, 3, y, mean, invstd, gamma, dy, nullptr, dgamma, dbeta, B * H * W, C, ws, ws_bytes,
+                            (hipStream_t)stream, ps);
 }
 
 int osi_bn_backward(const float* dout, const float* act, const float* y, const float* mean, const float* invstd,

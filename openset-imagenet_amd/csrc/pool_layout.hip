@@ -48,6 +48,44 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const f32x4* __restrict__ x
     idx[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
 }
 
+// Stem tail in one pass: pooled = maxpool3x3s2(relu(y * scale + shift)). The post-ReLU activation (the largest tensor of the
+// network, 411 MB at B = 128) is never written; bit 7 of each index byte records "maximum > 0", the only ReLU-gate information the
+// backward needs (gradient reaches a pixel only through a window whose maximum it is).
+__global__ __launch_bounds__(256) void k_bn_relu_maxpool_fwd(const f32x4* __restrict__ y, const f32x4* __restrict__ scale,
+                                                            const f32x4* __restrict__ shift, f32x4* __restrict__ pooled,
+                                                            uint32_t* __restrict__ idx, int B, int H, int W, int C4, int Ho, int Wo) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)B * Ho * Wo * C4;
+    if (i >= n) return;
+    int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    int wo = (int)(t % Wo); t /= Wo;
+    int ho = (int)(t % Ho);
+    int b = (int)(t / Ho);
+    const f32x4 sc = scale[c4], sh = shift[c4];
+    const float NEG = -__builtin_inff();
+    f32x4 best = {NEG, NEG, NEG, NEG};
+    uint32_t bi[4] = {0, 0, 0, 0};
+    bool first[4] = {true, true, true, true};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            int h = ho * 2 - 1 + r, w = wo * 2 - 1 + s;
+            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                f32x4 v = y[((size_t)(b * H + h) * W + w) * C4 + c4] * sc + sh;      // same expression as k_bn_apply
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (first[k] || v[k] > best[k]) { best[k] = v[k]; bi[k] = r * 3 + s; first[k] = false; }
+            }
+        }
+    pooled[i] = best;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bi[k] |= best[k] > 0.f ? 0x80u : 0u;
+    idx[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+}
+
 __global__ __launch_bounds__(256) void k_maxpool_bwd(const f32x4* __restrict__ dy, const uint32_t* __restrict__ idx, f32x4* __restrict__ dx,
                                                     int B, int H, int W, int C4, int Ho, int Wo) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -146,6 +184,17 @@ int osi_maxpool3x3s2_fwd(const float* x, float* y, void* idx, int B, int H, int 
     OSI_REQUIRE(n < (1ul << 31));
     hipLaunchKernelGGL(k_maxpool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, (f32x4*)y,
                        (uint32_t*)idx, B, H, W, C / 4, Ho, Wo);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+int osi_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* pooled, void* idx, int B, int H, int W,
+                            int C, osi_stream_t stream) {
+    OSI_REQUIRE(y && scale && shift && pooled && idx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    size_t n = (size_t)B * Ho * Wo * (C / 4);
+    OSI_REQUIRE(n < (1ul << 31));
+    hipLaunchKernelGGL(k_bn_relu_maxpool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)y,
+                       (const f32x4*)scale, (const f32x4*)shift, (f32x4*)pooled, (uint32_t*)idx, B, H, W, C / 4, Ho, Wo);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }

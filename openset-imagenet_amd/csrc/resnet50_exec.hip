@@ -193,7 +193,7 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
     n->x4 = n->ws_alloc((size_t)B * H * W * 4);
     n->wpack = n->ws_alloc(64 * 224);
     n->gpack = n->ws_alloc(64 * 224);
-    int stem = n->add_conv_bn(rb + "conv1", rb + "bn1", B, H, W, 4, 64, 7, 2, 3, true);
+    int stem = n->add_conv_bn(rb + "conv1", rb + "bn1", B, H, W, 4, 64, 7, 2, 3, false);   // its activation only exists max-pooled
     n->Hs = n->convs[stem].d.Ho; n->Ws = n->convs[stem].d.Wo;
     n->Hp = (n->Hs + 2 - 3) / 2 + 1; n->Wp = (n->Ws + 2 - 3) / 2 + 1;
     n->a_pool = n->ws_alloc((size_t)B * n->Hp * n->Wp * 64);
@@ -367,10 +367,9 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     n->mark(OSI_PROF_OTHER, st);
     OSI_TRY(conv_bn_fwd(n, 0, params, buffers, ws, ws + n->x4, ws + n->wpack, training, st, n->bn_ws));
     BN& b0 = n->bns[c0.bn];
-    OSI_TRY(osi_bn_apply_relu_mask(ws + c0.y, nullptr, ws + b0.scale, ws + b0.shift, ws + c0.a, ws + c0.mask, b0.M, 64, st));
+    // bn1 + relu + maxpool in one pass: the 112x112x64 post-ReLU tensor is never materialised
+    OSI_TRY(osi_bn_relu_maxpool_fwd(ws + c0.y, ws + b0.scale, ws + b0.shift, ws + n->a_pool, ws + n->pool_idx, n->B, n->Hs, n->Ws, 64, st));
     n->mark(OSI_PROF_BN_FWD, st);
-    OSI_TRY(osi_maxpool3x3s2_fwd(ws + c0.a, ws + n->a_pool, ws + n->pool_idx, n->B, n->Hs, n->Ws, 64, st));
-    n->mark(OSI_PROF_OTHER, st);
     // bottleneck blocks
     for (Block& k : n->blocks) {
         const float* x = ws + k.x_in;
@@ -641,10 +640,13 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             int go = n->cur_grad;
             int t = n->take(st);
             if (t < 0) return OSI_ERR_STATE;
-            OSI_TRY(osi_maxpool3x3s2_bwd(S(go), ws + n->pool_idx, S(t), n->B, n->Hs, n->Ws, 64, st));
-            n->mark(OSI_PROF_OTHER, st);
+            // max-pool scatter + ReLU gate + bn1 backward gathered on the fly from the pooled gradient (no 112x112x64 gradient)
+            BN& b0 = n->bns[c0.bn];
+            OSI_TRY(osi_bn_relu_maxpool_bwd(S(go), ws + n->pool_idx, ws + c0.y, ws + b0.mean, ws + b0.invstd, params + b0.g_off, S(t),
+                                            grads + b0.g_off, grads + b0.b_off, n->B, n->Hs, n->Ws, 64, ws + n->bn_ws, n->bn_ws_bytes, st));
+            n->mark(OSI_PROF_BN_BWD, st);
             n->give(go);
-            OSI_TRY(bn_conv_wgrad(n, 0, params, grads, ws, t, nullptr, ws + n->x4, st));
+            OSI_TRY(wgrad(n, 0, grads, ws, t, ws + n->x4, st));
             n->give(t);
             n->cur_grad = -1;
             n->fwd_done = false;

@@ -61,6 +61,8 @@ _SIGS = {
     "osi_resnet50_stage_input_u8": (c_int, [c_void_p, P, P, P, P]),
     "osi_maxpool3x3s2_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "osi_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "osi_bn_relu_maxpool_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "osi_bn_relu_maxpool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "osi_avgpool_fwd": (c_int, [P, P, c_int, c_int, c_int, P]),
     "osi_avgpool_bwd": (c_int, [P, P, c_int, c_int, c_int, P]),
     "osi_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
