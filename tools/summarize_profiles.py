@@ -72,6 +72,20 @@ def main():
         out[k] = {"fetch_GB_raw": round(fetch.get(k, 0) * 1024 / 1e9, 3),
                   "fetch_GB_x2_wide_read_correction": round(2 * fetch.get(k, 0) * 1024 / 1e9, 3),
                   "write_GB": round(write.get(k, 0) * 1024 / 1e9, 3)}
+    # achieved HBM-side bandwidth per kernel class = PMC bytes / rocprofv3 kernel time of the serialized run (no co-running kernels)
+    if os.path.isfile(ser):
+        steps_ser, tms = 0, defaultdict(float)
+        with open(ser) as fh:
+            for row in csv.DictReader(fh):
+                tms[klass(row["Name"])] += float(row["TotalDurationNs"]) / 1e6
+                if "k_adam" in row["Name"]:
+                    steps_ser = int(row["Calls"])
+        for k in list(out):
+            if k != "_note" and steps_ser and tms.get(k):
+                ms = tms[k] / steps_ser
+                out[k]["kernel_ms_per_step_serialized"] = round(ms, 3)
+                out[k]["achieved_TBps"] = round((out[k]["fetch_GB_x2_wide_read_correction"] + out[k]["write_GB"]) / ms, 3)
+        out["_note"] += "; achieved_TBps = (2*fetch + write) / summed kernel time of that class in the serialized rocprofv3 run (peak 8.0 spec / ~6.3 measured)"
     mf = os.path.join(src, "MfmaUtil", "p_counter_collection.csv")
     if os.path.isfile(mf):
         util = mfma_util_per_class(mf)
