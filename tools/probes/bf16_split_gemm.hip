@@ -33,17 +33,22 @@ __device__ __forceinline__ void split3(float v, unsigned& h0, unsigned& h1, unsi
     h0 = b0 >> 16; h1 = b1 >> 16; h2 = b2 >> 16;
 }
 
-// stage a [rows x 32] fp32 tile (row stride ld floats) into three bf16 LDS planes
-__device__ __forceinline__ void stage(const float* __restrict__ g, int ld, int rows_valid, unsigned short* s, int tid) {
-    // 128 rows x 8 float4 per row = 1024 float4, 4 per thread
+// global -> registers (issued before the MFMAs of the current K tile), registers -> three bf16 LDS planes (after them)
+__device__ __forceinline__ void gload(const float* __restrict__ g, int ld, int rows_valid, int tid, f32x4 (&v)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + 256 * i, row = f >> 3, q = f & 7;
-        f32x4 v = {0, 0, 0, 0};
-        if (row < rows_valid) v = *reinterpret_cast<const f32x4*>(g + (size_t)row * ld + q * 4);
+        v[i] = f32x4{0, 0, 0, 0};
+        if (row < rows_valid) v[i] = *reinterpret_cast<const f32x4*>(g + (size_t)row * ld + q * 4);
+    }
+}
+__device__ __forceinline__ void sstore(const f32x4 (&v)[4], unsigned short* s, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i, row = f >> 3, q = f & 7;
         unsigned h[3][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split3(v[e], h[0][e], h[1][e], h[2][e]);
+        for (int e = 0; e < 4; ++e) split3(v[i][e], h[0][e], h[1][e], h[2][e]);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             u32x2 w = {h[pl][0] | (h[pl][1] << 16), h[pl][2] | (h[pl][3] << 16)};
@@ -53,7 +58,7 @@ __device__ __forceinline__ void stage(const float* __restrict__ g, int ld, int r
 }
 
 template <int TERMS>
-__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+__global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
                                               int N, int K) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     unsigned short* sA = smem;                       // [3][BM][LDS_LD]
@@ -68,10 +73,14 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int r31 = lane & 31, h = lane >> 5;
+    f32x4 pa[4], pb[4];
+    const int mv = min(BM, M - m0), nv = min(BN, N - n0);
+    gload(A + (size_t)m0 * K, K, mv, tid, pa); gload(B + (size_t)n0 * K, K, nv, tid, pb);
+    sstore(pa, sA, tid); sstore(pb, sB, tid);
+    __syncthreads();
     for (int k0 = 0; k0 < K; k0 += BK) {
-        stage(A + (size_t)m0 * K + k0, K, min(BM, M - m0), sA, tid);
-        stage(B + (size_t)n0 * K + k0, K, min(BN, N - n0), sB, tid);
-        __syncthreads();
+        const bool more = k0 + BK < K;
+        if (more) { gload(A + (size_t)m0 * K + k0 + BK, K, mv, tid, pa); gload(B + (size_t)n0 * K + k0 + BK, K, nv, tid, pb); }
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 16) {
             bf16x8 a[2][3], b[2][3];
@@ -102,6 +111,8 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
                 }
         }
+        __syncthreads();
+        if (more) { sstore(pa, sA, tid); sstore(pb, sB, tid); }
         __syncthreads();
     }
 #pragma unroll
