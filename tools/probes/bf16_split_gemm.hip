@@ -57,9 +57,39 @@ __device__ __forceinline__ void sstore(const f32x4 (&v)[4], unsigned short* s, i
     }
 }
 
-template <int TERMS>
+// B (the weights) split ONCE into three bf16 planes in global memory, [3][N][K]: the GEMM then stages it without VALU work
+__global__ void k_presplit(const float* __restrict__ B, unsigned short* __restrict__ P, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned h0, h1, h2;
+    split3(B[i], h0, h1, h2);
+    P[i] = (unsigned short)h0; P[n + i] = (unsigned short)h1; P[2 * n + i] = (unsigned short)h2;
+}
+// planes -> registers: per thread 2 x 16-byte loads per plane (128 rows x 32 bf16 = 512 x 16 B, 2 per thread)
+__device__ __forceinline__ void gload_planes(const unsigned short* __restrict__ P, size_t plane_stride, int ld, int rows_valid, int tid,
+                                             uint4 (&v)[3][2]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i, row = f >> 2, q = f & 3;
+            v[pl][i] = uint4{0, 0, 0, 0};
+            if (row < rows_valid) v[pl][i] = *reinterpret_cast<const uint4*>(P + pl * plane_stride + (size_t)row * ld + q * 8);
+        }
+}
+__device__ __forceinline__ void sstore_planes(const uint4 (&v)[3][2], unsigned short* s, int tid) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i, row = f >> 2, q = f & 3;
+            *reinterpret_cast<uint4*>(s + (size_t)pl * BN * LDS_LD + row * LDS_LD + q * 8) = v[pl][i];
+        }
+}
+
+template <int TERMS, bool PRESPLIT>
 __global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
-                                              int N, int K) {
+                                              int N, int K, const unsigned short* __restrict__ BP) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     unsigned short* sA = smem;                       // [3][BM][LDS_LD]
     unsigned short* sB = smem + 3 * BM * LDS_LD;     // [3][BN][LDS_LD]
@@ -74,13 +104,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, co
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int r31 = lane & 31, h = lane >> 5;
     f32x4 pa[4], pb[4];
+    uint4 pp[3][2];
+    const size_t pstride = (size_t)N * K;
     const int mv = min(BM, M - m0), nv = min(BN, N - n0);
-    gload(A + (size_t)m0 * K, K, mv, tid, pa); gload(B + (size_t)n0 * K, K, nv, tid, pb);
-    sstore(pa, sA, tid); sstore(pb, sB, tid);
+    gload(A + (size_t)m0 * K, K, mv, tid, pa);
+    if (PRESPLIT) gload_planes(BP + (size_t)n0 * K, pstride, K, nv, tid, pp); else gload(B + (size_t)n0 * K, K, nv, tid, pb);
+    sstore(pa, sA, tid);
+    if (PRESPLIT) sstore_planes(pp, sB, tid); else sstore(pb, sB, tid);
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += BK) {
         const bool more = k0 + BK < K;
-        if (more) { gload(A + (size_t)m0 * K + k0 + BK, K, mv, tid, pa); gload(B + (size_t)n0 * K + k0 + BK, K, nv, tid, pb); }
+        if (more) {
+            gload(A + (size_t)m0 * K + k0 + BK, K, mv, tid, pa);
+            if (PRESPLIT) gload_planes(BP + (size_t)n0 * K + k0 + BK, pstride, K, nv, tid, pp); else gload(B + (size_t)n0 * K + k0 + BK, K, nv, tid, pb);
+        }
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 16) {
             bf16x8 a[2][3], b[2][3];
@@ -112,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, co
                 }
         }
         __syncthreads();
-        if (more) { sstore(pa, sA, tid); sstore(pb, sB, tid); }
+        if (more) { sstore(pa, sA, tid); if (PRESPLIT) sstore_planes(pp, sB, tid); else sstore(pb, sB, tid); }
         __syncthreads();
     }
 #pragma unroll
@@ -127,18 +164,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, co
             }
 }
 
-template <int TERMS>
+template <int TERMS, bool PRESPLIT = false>
 static void run(const float* dA, const float* dB, float* dC, int M, int N, int K, const std::vector<float>& A, const std::vector<float>& B,
-                const std::vector<int>& rows, const std::vector<double>& ref, double ref_scale, double fp32_err) {
+                const std::vector<int>& rows, const std::vector<double>& ref, double ref_scale, double fp32_err,
+                const unsigned short* dBP = nullptr) {
     const size_t smem = (size_t)3 * (BM + BN) * LDS_LD * sizeof(unsigned short);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<TERMS, PRESPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-    hipLaunchKernelGGL(k_gemm<TERMS>, grid, dim3(256), smem, 0, dA, dB, dC, M, N, K);
+    hipLaunchKernelGGL((k_gemm<TERMS, PRESPLIT>), grid, dim3(256), smem, 0, dA, dB, dC, M, N, K, dBP);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 20;
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_gemm<TERMS>, grid, dim3(256), smem, 0, dA, dB, dC, M, N, K);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_gemm<TERMS, PRESPLIT>), grid, dim3(256), smem, 0, dA, dB, dC, M, N, K, dBP);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     std::vector<float> Crow(N);
@@ -147,7 +185,7 @@ static void run(const float* dA, const float* dB, float* dC, int M, int N, int K
         hipMemcpy(Crow.data(), dC + (size_t)rows[ri] * N, N * sizeof(float), hipMemcpyDeviceToHost);
         for (int n = 0; n < N; ++n) err = fmax(err, fabs((double)Crow[n] - ref[ri * N + n]));
     }
-    printf("  bf16x%d: %7.3f ms  %7.1f TFLOP/s (fp32-equivalent)   max|err| / max|C| = %.3e   (plain fp32 FMA chain: %.3e)\n", TERMS, ms,
+    printf("  bf16x%d%s: %7.3f ms  %7.1f TFLOP/s (fp32-equivalent)   max|err| / max|C| = %.3e   (plain fp32 FMA chain: %.3e)\n", TERMS, PRESPLIT ? " (B pre-split)" : "", ms,
            2.0 * M * N * K / (ms * 1e-3) / 1e12, err / ref_scale, fp32_err / ref_scale);
 }
 
@@ -178,6 +216,11 @@ int main(int argc, char** argv) {
         run<3>(dA, dB, dC, M, N, K, A, B, rows, ref, scale, fp32_err);
         run<6>(dA, dB, dC, M, N, K, A, B, rows, ref, scale, fp32_err);
         run<9>(dA, dB, dC, M, N, K, A, B, rows, ref, scale, fp32_err);
+        unsigned short* dBP;
+        hipMalloc(&dBP, B.size() * 6);
+        hipLaunchKernelGGL(k_presplit, dim3((unsigned)((B.size() + 255) / 256)), dim3(256), 0, 0, dB, dBP, B.size());
+        run<6, true>(dA, dB, dC, M, N, K, A, B, rows, ref, scale, fp32_err, dBP);
+        hipFree(dBP);
         hipFree(dA); hipFree(dB); hipFree(dC);
     }
     return 0;
