@@ -71,6 +71,20 @@ def init_state(fc_layer_dim, out_features, logit_bias=False, dtype=torch.float32
     return ordered
 
 
+def randomize_bn(sd, generator=None):
+    """Replace the trivial BatchNorm initialisation (gamma 1, beta 0, running 0/1) by seeded random values so that parity
+    checks exercise the affine part and the eval-mode (running statistics) path. In place; returns sd."""
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            pre = k[:-len("running_mean")]
+            c = sd[k].numel()
+            sd[pre + "weight"] = (0.5 + torch.rand(c, generator=generator)).to(sd[k].dtype)
+            sd[pre + "bias"] = (0.2 * torch.randn(c, generator=generator)).to(sd[k].dtype)
+            sd[pre + "running_mean"] = (0.1 * torch.randn(c, generator=generator)).to(sd[k].dtype)
+            sd[pre + "running_var"] = (0.5 + torch.rand(c, generator=generator)).to(sd[k].dtype)
+    return sd
+
+
 def state_keys(logit_bias=False):
     """The 321 (+1 with logit bias) state_dict keys in torchvision / reference order."""
     keys = []
@@ -117,6 +131,7 @@ def forward(sd, image, training=True, taps=None):
             x = F.relu(out + identity)
             tap(f"layer{s + 1}.{b}", x)
     x = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+    tap("pooled", x)
     features = F.linear(x, sd["resnet_base.fc.weight"], sd["resnet_base.fc.bias"])
     logits = F.linear(features, sd["logits.weight"], sd.get("logits.bias"))
     return logits, features

@@ -144,3 +144,36 @@ def test_oscr_oracle_matches_reference(golden_dir):
         assert ccr.dtype == np.float64 and ccr.shape == G[f"{n}.ccr"].shape, n
         assert np.array_equal(ccr, G[f"{n}.ccr"], equal_nan=True), n
         assert np.array_equal(fpr, G[f"{n}.fpr"], equal_nan=True), n
+
+
+def test_oracle_body_matches_transformers_witness(golden_dir):
+    """The ResNet-50 body of the oracle against an INDEPENDENT implementation of the same published topology:
+    transformers' ResNetModel configured as ResNet-50 v1.5 (tests/golden/make_golden_witness.py, run in the dev container;
+    torchvision — the reference's own source of the body, model.py:17 — is not installed anywhere). The weights are
+    regenerated here from the same seeds; only the witness OUTPUTS are stored. fp64 on both sides, train and eval mode,
+    including the running-statistics update rule. Tolerance 1e-9 (pure summation-order noise in float64)."""
+    W = np.load(os.path.join(golden_dir, "resnet_witness.npz"))
+    assert len(W["names"]) >= 2
+    for tag in W["names"]:
+        B, HW, C, seed = (int(v) for v in W[f"{tag}.meta"])
+        gen = torch.Generator().manual_seed(seed)
+        sd = R.randomize_bn(R.init_state(C, C, False, generator=gen), gen)
+        x = torch.rand(B, 3, HW, HW, generator=gen).double()
+        for mode in ("train", "eval"):
+            work = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+            taps = {}
+            logits, feats = R.forward(work, x, mode == "train", taps)
+            p = f"{tag}.{mode}."
+            for name, got in (("pooled", taps["pooled"]), ("features", feats), ("logits", logits)):
+                ref = W[p + name]
+                assert got.shape == ref.shape, (p, name)
+                assert float(np.abs(got.numpy() - ref).max()) <= 1e-9 * max(1.0, float(np.abs(ref).max())), (p, name)
+            if mode == "train":
+                for key in W.files:
+                    if key.startswith(p + "resnet_base.") and key.endswith(("running_mean", "running_var")):
+                        assert np.allclose(work[key[len(p):]].numpy(), W[key], rtol=1e-10, atol=1e-12), key
+                        assert int(work[key[len(p):].rsplit(".", 1)[0] + ".num_batches_tracked"]) == 1
+        # the float32 oracle (the one the HIP path is compared with) stays within its usual noise of the witness
+        work = {k: v.clone() for k, v in sd.items()}
+        lg32, _ = R.forward(work, x.float(), True)
+        assert float(np.abs(lg32.double().numpy() - W[f"{tag}.train.logits"]).max()) <= 1e-4
