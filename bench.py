@@ -49,27 +49,70 @@ def synthetic_batch(B, C, p_neg, loss, device, seed):
     return images, labels.to(device)
 
 
-def cpu_baseline(C, p_neg, steps=2, B=32):
-    """The CPU oracle (torch-CPU restatement of the reference path) timed on this host's cores: fwd + loss + bwd + Adam."""
+def _cpu_leg(C, p_neg, loss, steps, B):
+    """One CPU-oracle leg: fwd + loss + bwd + Adam at batch B; returns (best step seconds, images/sec)."""
     from oracle import resnet50_oracle as R, losses_oracle as L
     torch.manual_seed(42)
     sd = R.init_state(C, C, False)
     g = torch.Generator().manual_seed(42)
     x = torch.rand(B, 3, 224, 224, generator=g)
     y = torch.randint(0, C, (B,), generator=g)
-    y[torch.rand(B, generator=g) < p_neg] = -1
+    if loss == "entropic":
+        y[torch.rand(B, generator=g) < p_neg] = -1
+        fn = lambda lg, t, f: L.entropic_openset_loss(lg, t, 1.0)
+    else:   # plain softmax cross-entropy on known classes only (negatives are removed from the training set, train.py:291-293)
+        fn = lambda lg, t, f: L.softmax_loss(lg, t)
     state, times = {}, []
-    fn = lambda lg, t, f: L.entropic_openset_loss(lg, t, 1.0)
     for i in range(steps + 1):
         t0 = time.perf_counter()
         _, _, _, grads = R.forward_backward(sd, x, y, fn)
         R.adam_step(sd, grads, state, lr=1e-3)
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
-    return {"value": round(B / best, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return best, B / best
+
+
+def cpu_baseline(C, p_neg, steps=2, B=32):
+    """The CPU oracle (torch-CPU restatement of the reference path) timed on this host's cores, the two legs SURVEY.md §8(d) names:
+    the GPU workload's own loss at B = 32 (`value`) and BASELINE.json config 1 (Protocol 1, C = 116, softmax cross-entropy, B = 32)."""
+    best, ips = _cpu_leg(C, p_neg, "entropic", steps, B)
+    best1, ips1 = _cpu_leg(116, 0.0, "softmax", 1, B)
+    return {"value": round(ips, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} timed steps (after 1 warm-up) of batch {B}, same shapes/loss as the GPU workload, best step {best:.2f} s; "
                       f"oracle/resnet50_oracle.py (torch-CPU fp32 restatement; the reference package itself is not importable offline)",
+            "config1_protocol1_softmax_b32": {"value": round(ips1, 3), "unit": "images/sec",
+                                              "sample": f"1 timed step (after 1 warm-up) of batch {B}, C = 116, softmax cross-entropy, Adam; "
+                                                        f"step {best1:.2f} s (BASELINE.json configs[0])"},
             "host_cpu_count": os.cpu_count()}
+
+
+def _git_blob_id(path):
+    """sha1 of the file as `git hash-object` computes it (no git needed on the GPU box): ties a number to the committed profile."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def committed_traffic(ms_step, B, workload):
+    """HBM-side bytes per step of the conv kernels from the newest committed PMC summary (profiles/rNN_hbm_traffic_per_step.json),
+    with its provenance: file, git blob id, the step time / workload the profile was taken at, and whether that still matches
+    the run being reported (a stale or foreign profile yields traffic = None instead of a silently re-reported number)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_per_step.json")))
+    if not files:
+        return None, {"file": None}
+    path = files[-1]
+    t = json.load(open(path))
+    meta = t.get("_meta", {})
+    prov = {"file": os.path.relpath(path, ROOT), "git_blob": _git_blob_id(path), "profiled_ms_per_step": meta.get("ms_per_step"),
+            "profiled_workload": meta.get("workload"), "profiled_commit": meta.get("commit")}
+    same = meta.get("workload") == workload and meta.get("batch") == B
+    fresh = same and meta.get("ms_per_step") and abs(meta["ms_per_step"] - ms_step) <= 0.15 * ms_step
+    prov["matches_this_run"] = bool(fresh)
+    if not fresh:
+        return None, prov
+    total = sum(t[k]["fetch_GB_x2_wide_read_correction"] + t[k]["write_GB"] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
+    return round(total * 1e9), prov
 
 
 def parity_probe(model, C, device):
@@ -211,7 +254,7 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (device-resident U[0,1) images, random-init weights seed 42)",
-            "config": {"workload": wl["name"], "classes": C, "batch_per_gpu": B, "global_batch": B * world, "image": "3x224x224",
+            "config": {"workload": wl["name"], "workload_key": args.workload, "classes": C, "batch_per_gpu": B, "global_batch": B * world, "image": "3x224x224",
                        "loss": wl["loss"], "optimizer": "adam lr=1e-3", "parallelism": f"dp{world}"},
             "final_loss": round(loss_value, 5),
             "step_mfma_frac": round(B * args.steps / elapsed * CONV_GFLOP_PER_IMAGE * 1e9 / (MFMA_F32_PEAK_TFLOPS * 1e12), 4),
@@ -222,16 +265,14 @@ def main():
             # HBM-side traffic of the conv kernels per step cannot be read from inside the process; it is the rocprofv3 PMC
             # measurement of this same command committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE, KiB units, the x2 is the
             # gfx950 wide-read correction of MI355X_MICROARCH.md, validated on the Adam kernel's known 380/285 MB).
-            traffic, tpath = None, os.path.join(ROOT, "profiles", "r01_hbm_traffic_per_step.json")
-            if os.path.isfile(tpath) and B == 128 and args.workload == "p2":
-                t = json.load(open(tpath))
-                traffic = round(sum(t[k]["fetch_GB_x2_wide_read_correction"] + t[k]["write_GB"]
-                                    for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")) * 1e9)
+            traffic, tprov = committed_traffic(ms_step, B, args.workload)
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "bytes per step at the L2<->fabric boundary for the three conv kernel classes, from "
-                                "profiles/r01_hbm_traffic_per_step.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes); "
+                "traffic_provenance": tprov,
+                "traffic_note": "bytes per step at the L2<->fabric boundary for the three conv kernel classes, from the committed "
+                                "rocprofv3 PMC summary named in traffic_provenance (--pmc FETCH_SIZE / WRITE_SIZE, separate passes); null "
+                                "when that profile was taken on another workload or its step time is >15% off this run (stale); "
                                 "algorithmic minimum ~36e9 (each conv input/output once fwd, dY+W / dY+X bwd)",
                 "kernel": "implicit-GEMM conv (k_conv_fwd + k_conv_dgrad + k_conv_wgrad incl. split-K reduce), fp32 MFMA 32x32x2",
                 "how": f"24.287 GFLOP/img x {B} img per step / summed HIP-event duration of the conv launches per step ({conv_ms:.2f} ms), "

@@ -34,6 +34,12 @@ typedef void* osi_stream_t; /* hipStream_t */
 int osi_abi_version(void);            /* bumped on any signature change */
 const char* osi_build_arch(void);     /* "gfx950" */
 const char* osi_strerror(int code);
+/* Process-wide development knobs (A/B measurements; the defaults are the measured optimum). Launch functions only READ them and
+ * never consult the environment. Names: "wgrad_tile" (64 = force 64x64 weight-gradient tiles), "wgrad_blocks" (split-K footprint
+ * budget), "wgrad_nst" (LDS stages, 1|2), "wgrad_group" (XCD co-scheduling of the filter taps, 0|1), "bn_grid" (grid cap of the
+ * BatchNorm stream kernels). Unknown name / out-of-range value -> OSI_ERR_ARG. Not meant to be changed while launches are in flight. */
+int osi_set_tuning(const char* name, int value);
+int osi_get_tuning(const char* name, int* value);
 
 /* ---- convolution (torchvision.models.resnet50 body constructed at openset_imagenet/model.py:17, run at model.py:37) --- */
 typedef struct {
@@ -129,6 +135,13 @@ int osi_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int B, int H, int W,
  * (RandomHorizontalFlip, train.py:262; flip may be NULL), 4th channel zero: the input pipeline's last mile on the device. */
 int osi_u8hwc3_to_nhwc4(const unsigned char* x_u8_nhwc, const unsigned char* flip, float* y_nhwc4, int B, int H, int W,
                         osi_stream_t stream);
+/* The device side of the reference's input transform Compose([Resize(256), RandomCrop(224) | CenterCrop(224), RandomHorizontalFlip,
+ * ToTensor]) (train.py:259-268) after decode + resize: canvas = uint8 [B][Hc][Wc][3] holding the resized image (or a window of it
+ * that contains the crop), crop_xy = int32 [B][2] top-left corner (x0, y0) of the HxW crop inside the canvas (NULL = (0, 0); values
+ * are clamped on the device into the valid range, in place), flip[b] != 0 mirrors the CROPPED image (NULL = none);
+ * y = fp32 [B][H][W][4], value / 255, 4th channel zero. */
+int osi_u8_crop_flip_to_nhwc4(const unsigned char* canvas_u8, int* crop_xy, const unsigned char* flip, float* y_nhwc4, int B, int Hc,
+                              int Wc, int H, int W, osi_stream_t stream);
 /* idx: B*Ho*Wo*C bytes (argmax position 0..8 per element) */
 int osi_maxpool3x3s2_fwd(const float* x, float* y, void* idx, int B, int H, int W, int C, osi_stream_t stream);
 int osi_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, int B, int H, int W, int C, osi_stream_t stream);
@@ -163,6 +176,10 @@ int osi_softmax(const float* logits, float* out, int B, int C, osi_stream_t stre
  * last_valid_class: 0 = all columns (Python None), negative = Python negative slice end (-1: drop the background column). */
 int osi_confidence_accumulate(const float* logits, const long long* target, int B, int C, float offset, long long unknown_class,
                               int last_valid_class, double* acc4, osi_stream_t stream);
+/* the same sums from a matrix of softmax SCORES, i.e. metrics.confidence(scores, target_labels, offset, unknown_class,
+ * last_valid_class) itself (metrics.py:8-42) */
+int osi_confidence_from_scores(const float* scores, const long long* target, int B, int C, float offset, long long unknown_class,
+                               int last_valid_class, double* acc4, osi_stream_t stream);
 
 /* Open-Set Classification Rate curve, util.calculate_oscr (util.py:90-122), on device-resident scores[N][C] (f32 or f64) and
  * int64 labels. Outputs: taus[0 .. totals[0]) = the distinct target-class scores of the known samples in ascending order;
@@ -215,8 +232,12 @@ int osi_resnet50_stage_grad_range(osi_resnet50_t net, int s, size_t* lo, size_t*
  * `workspace`); the next osi_resnet50_forward on that workspace passes image = NULL (OSI_ERR_STATE without a staged input). */
 int osi_resnet50_stage_input_u8(osi_resnet50_t net, const unsigned char* images_u8_nhwc, const unsigned char* flip,
                                 void* workspace, osi_stream_t stream);
-/* image: [B][3][H][W] fp32 NCHW as the reference feeds it (or NULL after osi_resnet50_stage_input_u8). training != 0: batch
- * statistics + running-stat update. */
+/* Alternative to staging: bind an NHWC4 fp32 batch [B][H][W][4] that already lives in device memory (e.g. written by
+ * osi_u8_crop_flip_to_nhwc4 on a copy stream, one batch ahead); the next osi_resnet50_forward with image = NULL reads it in place
+ * and that step's stem weight gradient reads it again, so it must stay untouched until the step's backward has run. */
+int osi_resnet50_bind_input_nhwc4(osi_resnet50_t net, const float* x_nhwc4);
+/* image: [B][3][H][W] fp32 NCHW as the reference feeds it (or NULL after osi_resnet50_stage_input_u8 /
+ * osi_resnet50_bind_input_nhwc4). training != 0: batch statistics + running-stat update. */
 int osi_resnet50_forward(osi_resnet50_t net, const float* params, float* buffers, long long* nbt, const float* image,
                          void* workspace, float* logits, float* features, int training, osi_stream_t stream);
 /* runs backward stages [stage_lo, stage_hi) given dJ/dlogits and (optionally, may be NULL) dJ/dfeatures */
@@ -226,6 +247,10 @@ int osi_resnet50_backward(osi_resnet50_t net, const float* params, float* grads,
 /* Weight gradients on a low-priority side stream, overlapped with dgrad / BatchNorm backward (default on; joined back into
  * `stream` at the end of every backward stage). enable = 0 serialises everything on the caller's stream. */
 int osi_resnet50_set_overlap(osi_resnet50_t net, int enable);
+/* Per-executor switches: "overlap" (= osi_resnet50_set_overlap), "fwd_fork" (projection shortcut of the forward pass on the side
+ * stream, default 1), "side_priority_normal" (side stream at default instead of lowest priority; only before the first training
+ * call, else OSI_ERR_STATE). Unknown name -> OSI_ERR_ARG. */
+int osi_resnet50_set_option(osi_resnet50_t net, const char* name, int value);
 
 /* Optional HIP-event instrumentation of the executor (bench.py's roofline leg): one event after every op on the launch
  * stream, attributed to a kernel class. profile_read synchronises on the last event — call it outside timed regions. */

@@ -1,8 +1,39 @@
 // ABI bookkeeping for libosi_hip.so.
 #include "osi_common.h"
 
+#include <cstring>
+
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*wgrad_group*/ 1};
+
+namespace {
+int* tuning_slot(const char* name) {
+    if (!name) return nullptr;
+    if (!strcmp(name, "wgrad_tile")) return &g_osi_tuning.wgrad_tile;
+    if (!strcmp(name, "wgrad_blocks")) return &g_osi_tuning.wgrad_blocks;
+    if (!strcmp(name, "wgrad_nst")) return &g_osi_tuning.wgrad_nst;
+    if (!strcmp(name, "bn_grid")) return &g_osi_tuning.bn_grid;
+    if (!strcmp(name, "wgrad_group")) return &g_osi_tuning.wgrad_group;
+    return nullptr;
+}
+}  // namespace
+
 extern "C" {
-int osi_abi_version(void) { return 1; }
+int osi_abi_version(void) { return 2; }
+int osi_set_tuning(const char* name, int value) {
+    int* s = tuning_slot(name);
+    if (!s) return OSI_ERR_ARG;
+    if (s == &g_osi_tuning.wgrad_blocks && value < 1) return OSI_ERR_ARG;
+    if (s == &g_osi_tuning.wgrad_nst && value != 1 && value != 2) return OSI_ERR_ARG;
+    if (s == &g_osi_tuning.bn_grid && value < 1) return OSI_ERR_ARG;
+    *s = value;
+    return OSI_OK;
+}
+int osi_get_tuning(const char* name, int* value) {
+    int* s = tuning_slot(name);
+    if (!s || !value) return OSI_ERR_ARG;
+    *value = *s;
+    return OSI_OK;
+}
 const char* osi_build_arch(void) { return "gfx950"; }
 const char* osi_strerror(int code) {
     switch (code) {

@@ -10,7 +10,6 @@
 // Statistics use shifted sums per workgroup (shift = first row of the chunk) and a weighted Chan merge of
 // the per-workgroup (mean, M2), so there is no E[x^2]-E[x]^2 cancellation in fp32.
 #include "osi_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -423,7 +422,7 @@ static int rows_per_block(int M, int C, int& P) {
 // 4 workgroups (16 waves) per CU stream at the HBM rate and leave half of every CU's wave slots, and all of its LDS, to the
 // weight-gradient kernels that run concurrently on the executor's side stream.
 static int stream_grid(size_t n4) {
-    static const size_t cap = getenv("OSI_BN_GRID") ? (size_t)atoi(getenv("OSI_BN_GRID")) : 1024;  // dev A/B switch
+    const size_t cap = (size_t)g_osi_tuning.bn_grid;
     size_t g = (n4 + NT - 1) / NT;
     return (int)(g > cap ? cap : g);
 }

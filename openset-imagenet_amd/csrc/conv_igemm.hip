@@ -14,8 +14,9 @@
 //   wgrad  dW[n, (r,s,c)] = sum_m dY[m, n] * im2col(X)[m, (r,s,c)]            k=m (split across blocks)
 //
 // One workgroup = 4 waves in a 2x2 grid; each wave owns WM x WN MFMA tiles of 32x32, K-step 32 per
-// LDS stage, two LDS stages, register-staged global->LDS copies (the im2col gather and zero padding
-// happen in registers), one barrier per K tile.
+// LDS stage, register-staged global->LDS copies through buffer (SRSRC) loads whose range check is the im2col
+// zero padding. NST LDS stages: 1 (default: single buffered, two barriers per K tile, twice the resident
+// workgroups) or 2 (double buffered, one barrier per K tile).
 //
 // LDS operand images
 //   "R" image  [rows][32 + 4]  k contiguous, read with ds_read_b128 (conflict-free at a 36-float row stride)
@@ -23,7 +24,6 @@
 // The K order inside a stage is permuted identically for both operands (lane half h of MFMA (j,e) consumes
 // k = 8j + 4h + e), which a dot product does not care about.
 #include "osi_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -57,6 +57,7 @@ struct ConvP {
     // wgrad only
     int kchunk;       // pixels per split
     int wtbl;         // generic loader: rolling table of input byte offsets in LDS instead of per-row divisions
+    int wgroup, splits;  // XCD-aware (cell, tap) block mapping on a 1-D grid; number of K splits
     size_t slab_stride;
 };
 
@@ -655,9 +656,26 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // tiles: rows over cout (MT), cols over (tap, cin tile) (NT)
-    const int bid = blockIdx.x;
-    const int mt = bid % p.MT, ntile = bid / p.MT;
+    // tiles: rows over cout (MT), cols over (tap, cin tile) (NT), K splits
+    int mt, ntile, split;
+    if (p.wgroup) {
+        // XCD-aware cell mapping: the R*S tap workgroups of one (cout tile, cin tile, K split) cell read the SAME dY chunk and
+        // overlapping windows of the same X chunk. Workgroups b and b+8 share an XCD, so the taps of a cell take consecutive
+        // dispatch slots of one XCD: the first one pulls the chunk from HBM, the others hit that XCD's L2.
+        const int taps = STEM ? 1 : p.R * p.S;
+        const int ctiles = p.NT / taps;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int tp = slot % taps;
+        const int cell = (slot / taps) * 8 + xcd;
+        if (cell >= p.MT * ctiles * p.splits) return;
+        mt = cell % p.MT;
+        const int rest = cell / p.MT;
+        const int ct = rest % ctiles;
+        split = rest / ctiles;
+        ntile = tp * ctiles + ct;
+    } else {
+        mt = blockIdx.x % p.MT; ntile = blockIdx.x / p.MT; split = blockIdx.y;
+    }
     const int n0 = mt * BM;  // cout offset
     int tap = 0, c0 = 0, r = 0, s = 0;
     if (!STEM) {
@@ -665,7 +683,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
         tap = ntile / ctiles; c0 = (ntile - tap * ctiles) * BN;
         r = tap / p.S; s = tap - r * p.S;
     }
-    const int kbeg = blockIdx.y * p.kchunk;
+    const int kbeg = split * p.kchunk;
     const int kend = min(p.M, kbeg + p.kchunk);
     const int T = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
@@ -767,7 +785,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
         }
     }
 
-    float* out = p.y + (size_t)blockIdx.y * p.slab_stride;
+    float* out = p.y + (size_t)split * p.slab_stride;
     const int colbase = STEM ? ntile * BN : tap * p.Cin + c0;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -909,7 +927,16 @@ static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
     p.wtbl = (!STEM && !p.unit) ? 1 : 0;
     if (p.wtbl) smem += 32 * BK * sizeof(uint32_t);   // TW * BK offsets
     if (int e = set_smem(k_conv_wgrad<WM, WN, STEM, NST>, smem)) return e;
-    hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST>), dim3(p.MT * p.NT, splits), dim3(256), smem, st, p);
+    p.splits = splits;
+    p.wgroup = (g_osi_tuning.wgrad_group != 0) ? 1 : 0;
+    if (p.wgroup) {
+        const int taps = STEM ? 1 : p.R * p.S;
+        const long cells = (long)p.MT * (p.NT / taps) * splits;
+        const long grid = (cells + 7) / 8 * 8 * taps;
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST>), dim3((unsigned)grid), dim3(256), smem, st, p);
+    } else {
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST>), dim3(p.MT * p.NT, splits), dim3(256), smem, st, p);
+    }
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
@@ -919,10 +946,10 @@ struct WgradPlan { int wm, wn, splits, kchunk; };
 static WgradPlan plan_wgrad(const osi_conv_desc* d) {
     WgradPlan w;
     const bool stem = is_stem(d);
-    // 128-wide tiles wherever the channel counts allow (OSI_WGRAD_TILE=64 forces 64x64 for A/B runs). Measured with the footprint
+    // 128-wide tiles wherever the channel counts allow (osi_set_tuning("wgrad_tile", 64) forces 64x64 for A/B runs). Measured with the footprint
     // budget below: 64x64 everywhere is ~8 % faster ALONE (wgrad class 11.1 -> 10.2 ms/step) but 0.4 ms slower inside the
     // overlapped step (36.7-37.0 vs 36.3 ms): six short-lived small workgroups per CU disturb the dgrad chain more than two big ones.
-    static const int big = getenv("OSI_WGRAD_TILE") ? atoi(getenv("OSI_WGRAD_TILE")) != 64 : 1;
+    const int big = g_osi_tuning.wgrad_tile != 64;
     w.wm = (big && d->Cout % 128 == 0) ? 2 : 1;
     w.wn = (big && !stem && d->Cin % 128 == 0) ? 2 : 1;
     const int BMg = 64 * w.wm, BNg = 64 * w.wn;
@@ -932,8 +959,8 @@ static WgradPlan plan_wgrad(const osi_conv_desc* d) {
     // Footprint budget per launch in units of 64x64 workgroups (a 128x128 workgroup counts as four): 2048 = two 128x128 or eight
     // 64x64 workgroups per CU. Alone, twice that is ~10 % faster, but the weight gradients run on the executor's side stream next
     // to the data-gradient chain and must leave half of each CU's LDS, registers and wave slots to the critical path: the whole
-    // step is 0.7 ms shorter this way (sweep in DESIGN.md §3). OSI_WGRAD_BLOCKS overrides (development).
-    static const int target64 = getenv("OSI_WGRAD_BLOCKS") ? atoi(getenv("OSI_WGRAD_BLOCKS")) : 2048;
+    // step is 0.7 ms shorter this way (sweep in DESIGN.md §3). osi_set_tuning("wgrad_blocks", n) overrides (development).
+    const int target64 = g_osi_tuning.wgrad_blocks;
     const int target = target64 / (w.wm * w.wn);
     long splits = (target + tiles - 1) / tiles;
     long maxs = (M + 8 * BK - 1) / (8 * BK);                // at least 8 K tiles per split (amortises the 64 KiB slab tile)
@@ -1082,12 +1109,6 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     }
 }
 
-// Development switches (environment, read once): OSI_WGRAD_NST=1|2 LDS stages, OSI_WGRAD_TILE=64 forces 64x64 tiles.
-static int wgrad_env(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 size_t osi_conv_wgrad_workspace(const osi_conv_desc* d) {
     if (!desc_ok(d)) return 0;
     WgradPlan w = plan_wgrad(d);
@@ -1114,7 +1135,7 @@ int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, floa
     int e;
     // Single-buffered LDS by default (as in fwd/dgrad: twice the resident workgroups beat staging depth): 11.4 -> 10.3 ms per step
     // for the wgrad class and -0.45 ms on the overlapped step, measured with the side-stream schedule of the executor.
-    static const int nst = wgrad_env("OSI_WGRAD_NST", 1);
+    const int nst = g_osi_tuning.wgrad_nst;
     if (stem) e = launch_wgrad<1, 1, true>(p, w.splits, st);
     else if (w.wm == 2 && w.wn == 2) e = nst == 1 ? launch_wgrad<2, 2, false, 1>(p, w.splits, st) : launch_wgrad<2, 2, false>(p, w.splits, st);
     else if (w.wm == 2) e = nst == 1 ? launch_wgrad<2, 1, false, 1>(p, w.splits, st) : launch_wgrad<2, 1, false>(p, w.splits, st);

@@ -129,6 +129,8 @@ __global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ z, fl
 // over the batches of an epoch instead of materialising the [N_val, C] score matrix: acc[0] += sum of softmax(z)[y] over known
 // rows (y >= 0, y != unknown_class), acc[1] += their count, acc[2] += sum over rows with y == unknown_class of
 // (1 + offset - max_{c < n_valid} softmax(z)[c]), acc[3] += their count. One workgroup, fixed order, double accumulators.
+// SCORES: z already holds softmax scores (metrics.confidence's own argument) instead of logits.
+template <bool SCORES>
 __global__ __launch_bounds__(LOSS_THREADS) void k_confidence(const float* __restrict__ z, const long long* __restrict__ y, int B, int C,
                                                             float offset, long long unknown_class, int n_valid, double* acc) {
     __shared__ double red[4][LOSS_WAVES];
@@ -140,6 +142,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_confidence(const float* __rest
         float mx = -__builtin_inff(), mv = -__builtin_inff();
         for (int c = lane; c < C; c += 64) { float v = zr[c]; mx = fmaxf(mx, v); if (c < n_valid) mv = fmaxf(mv, v); }
         mx = wave_max(mx); mv = wave_max(mv);
+        if (SCORES) {
+            if (yi == unknown_class) { ns += (double)(1.0f + offset - mv); nc += 1; }
+            else if (yi >= 0 && yi < C) { ks += (double)zr[yi]; kc += 1; }
+            continue;
+        }
         float se = 0.f;
         for (int c = lane; c < C; c += 64) se += expf(zr[c] - mx);
         se = wave_sum(se);
@@ -165,7 +172,18 @@ int osi_confidence_accumulate(const float* logits, const long long* target, int 
     // python slicing scores[:, :last_valid_class]: None (encoded as 0 here) = all C columns, negative = C + last_valid_class
     const int n_valid = last_valid_class == 0 ? C : (last_valid_class < 0 ? C + last_valid_class : last_valid_class);
     OSI_REQUIRE(n_valid > 0 && n_valid <= C);
-    hipLaunchKernelGGL(k_confidence, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, logits, target, B, C, offset,
+    hipLaunchKernelGGL(k_confidence<false>, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, logits, target, B, C, offset,
+                       unknown_class, n_valid, acc4);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+int osi_confidence_from_scores(const float* scores, const long long* target, int B, int C, float offset, long long unknown_class,
+                               int last_valid_class, double* acc4, osi_stream_t stream) {
+    OSI_REQUIRE(scores && target && acc4 && B > 0 && C > 0);
+    const int n_valid = last_valid_class == 0 ? C : (last_valid_class < 0 ? C + last_valid_class : last_valid_class);
+    OSI_REQUIRE(n_valid > 0 && n_valid <= C);
+    hipLaunchKernelGGL(k_confidence<true>, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, scores, target, B, C, offset,
                        unknown_class, n_valid, acc4);
     OSI_LAUNCH_CHECK();
     return OSI_OK;

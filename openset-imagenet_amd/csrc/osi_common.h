@@ -19,6 +19,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (!(cond)) return OSI_ERR_ARG;                       \
     } while (0)
 
+// Process-wide tuning knobs (development A/B switches). Written only by osi_set_tuning() (abi.hip); launch functions read them
+// and never touch the environment, so they stay stateless and re-entrant as include/osi.h promises. Defaults = measured optimum.
+struct OsiTuning {
+    int wgrad_tile;     // 64 forces 64x64 weight-gradient tiles, 0 = 128-wide tiles wherever the channel counts allow
+    int wgrad_blocks;   // split-K footprint budget of one weight-gradient launch, in 64x64-workgroup units
+    int wgrad_nst;      // LDS stages of the weight-gradient kernel (1 or 2)
+    int bn_grid;        // grid cap of the BatchNorm stream kernels
+    int wgrad_group;    // 1 = co-schedule the R*S tap workgroups of one (cout, cin, split) cell on one XCD
+};
+extern OsiTuning g_osi_tuning;
+
 static inline int osi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Unsigned division by a runtime-constant divisor: q = (n * mul) >> (32 + sh), exact for n < 2^31.

@@ -12,7 +12,6 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
-#include <cstdlib>
 
 #define OSI_TRY(x)                 \
     do {                           \
@@ -86,11 +85,17 @@ struct osi_resnet50 {
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_cls;
     int prof_n = 0;
-    void mark(int cls, hipStream_t st) {
-        if (!prof_on) return;
-        if (prof_n == (int)prof_ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; prof_ev.push_back(e); prof_cls.push_back(0); }
+    int mark(int cls, hipStream_t st) {
+        if (!prof_on) return OSI_OK;
+        if (prof_n == (int)prof_ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return OSI_ERR_LAUNCH;
+            prof_ev.push_back(e); prof_cls.push_back(0);
+        }
         prof_cls[prof_n] = cls;
-        (void)hipEventRecord(prof_ev[prof_n++], st);
+        if (hipEventRecord(prof_ev[prof_n], st) != hipSuccess) return OSI_ERR_LAUNCH;
+        ++prof_n;
+        return OSI_OK;
     }
 
     size_t add_tensor(const std::string& name, int ndim, const int* shape) {
@@ -135,6 +140,10 @@ struct osi_resnet50 {
     // or in the ragged last round of a dgrad launch. buf_ev[i] = last side-stream reader of scratch buffer i.
     void* staged_ws = nullptr;   // workspace whose input buffer was filled by osi_resnet50_stage_input_u8 (consumed by one forward)
     bool overlap = true;
+    bool fwd_fork = true;            // projection shortcut of the forward pass on the side stream
+    bool side_prio_normal = false;   // side stream at default instead of lowest priority (read when the stream is created)
+    const float* x4_ext = nullptr;   // external NHWC4 input bound by osi_resnet50_bind_input_nhwc4 (consumed by one forward)
+    const float* x4_cur = nullptr;   // input of the step in flight (forward sets it, the stem weight gradient reads it)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t buf_ev[NSCR] = {};
@@ -144,8 +153,7 @@ struct osi_resnet50 {
         if (side) return OSI_OK;
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return OSI_ERR_LAUNCH;
-        const char* pr = getenv("OSI_SIDE_PRIO");  // dev A/B switch: "normal" gives the side stream the default priority
-        const int prio = (pr && pr[0] == 'n') ? 0 : lo;
+        const int prio = side_prio_normal ? 0 : lo;   // option "side_priority_normal": default priority for the side stream (A/B)
         if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio) != hipSuccess) return OSI_ERR_LAUNCH;
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
         if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
@@ -155,11 +163,15 @@ struct osi_resnet50 {
     }
     bool async_wgrad() const { return overlap && !prof_on && side != nullptr; }
     // a scratch buffer may only be rewritten on `st` after its last side-stream reader has finished
+    // returns the buffer index, or a negative OSI_ERR_* code
     int take(hipStream_t st) {
-        if (free_list.empty()) return -1;
+        if (free_list.empty()) return OSI_ERR_STATE;
         // FIFO: hand out the buffer that was released longest ago, so its side-stream reader has most likely finished
         int i = free_list.front(); free_list.erase(free_list.begin());
-        if (buf_pending[i]) { (void)hipStreamWaitEvent(st, buf_ev[i], 0); buf_pending[i] = false; }
+        if (buf_pending[i]) {
+            if (hipStreamWaitEvent(st, buf_ev[i], 0) != hipSuccess) return OSI_ERR_LAUNCH;
+            buf_pending[i] = false;
+        }
         return i;
     }
     void give(int i) { free_list.push_back(i); }
@@ -325,17 +337,17 @@ static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buff
         // batch statistics come out of the conv epilogue (per row tile), only a tiny per-channel merge follows
         int P = 0, rows = 0;
         OSI_TRY(osi_conv_fwd_bnstats(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
-        n->mark(OSI_PROF_CONV_FWD, st);
+        OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
         OSI_TRY(osi_bn_finalize_stats(ws + bn_ws_off, n->bn_ws_bytes, P, rows, b.M, b.C, params + b.g_off, params + b.b_off, 1e-5f, 0.1f,
                                       buffers + b.rm_off, buffers + b.rv_off, ws + b.mean, ws + b.invstd, ws + b.scale,
                                       ws + b.shift, st));
     } else {
         OSI_TRY(osi_conv_fwd(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, st));
-        n->mark(OSI_PROF_CONV_FWD, st);
+        OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
         OSI_TRY(osi_bn_eval_coeffs(buffers + b.rm_off, buffers + b.rv_off, params + b.g_off, params + b.b_off, 1e-5f, b.C,
                                    ws + b.scale, ws + b.shift, st));
     }
-    n->mark(OSI_PROF_BN_FWD, st);
+    OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
     return OSI_OK;
 }
 
@@ -349,27 +361,37 @@ int osi_resnet50_stage_input_u8(osi_resnet50_t n, const unsigned char* images_u8
     return OSI_OK;
 }
 
+int osi_resnet50_bind_input_nhwc4(osi_resnet50_t n, const float* x_nhwc4) {
+    OSI_REQUIRE(n && x_nhwc4 && ((size_t)x_nhwc4 & 15) == 0);
+    n->x4_ext = x_nhwc4;
+    return OSI_OK;
+}
+
 int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, long long* nbt, const float* image,
                          void* workspace, float* logits, float* features, int training, osi_stream_t stream) {
     OSI_REQUIRE(n && params && buffers && workspace && logits && features);
     OSI_REQUIRE(!training || nbt);
-    if (!image && n->staged_ws != workspace) return OSI_ERR_STATE;   // image = NULL needs osi_resnet50_stage_input_u8 on this workspace
+    const float* ext = n->x4_ext;
+    n->x4_ext = nullptr;
+    if (!image && !ext && n->staged_ws != workspace) return OSI_ERR_STATE;   // image = NULL needs a staged or bound input
     n->staged_ws = nullptr;
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
+    const float* x4 = (!image && ext) ? ext : ws + n->x4;
+    n->x4_cur = x4;
     n->fwd_done = false;
     if (training && n->overlap && !n->prof_on) OSI_TRY(n->ensure_side());
-    n->mark(OSI_PROF_START, st);
+    OSI_TRY(n->mark(OSI_PROF_START, st));
     // stem
     if (image) OSI_TRY(osi_nchw3_to_nhwc4(image, ws + n->x4, n->B, n->H, n->W, st));
     Conv& c0 = n->convs[0];
     OSI_TRY(osi_stem_weight_pack(params + c0.w_off, ws + n->wpack, 64, st));
-    n->mark(OSI_PROF_OTHER, st);
-    OSI_TRY(conv_bn_fwd(n, 0, params, buffers, ws, ws + n->x4, ws + n->wpack, training, st, n->bn_ws));
+    OSI_TRY(n->mark(OSI_PROF_OTHER, st));
+    OSI_TRY(conv_bn_fwd(n, 0, params, buffers, ws, x4, ws + n->wpack, training, st, n->bn_ws));
     BN& b0 = n->bns[c0.bn];
     // bn1 + relu + maxpool in one pass: the 112x112x64 post-ReLU tensor is never materialised
     OSI_TRY(osi_bn_relu_maxpool_fwd(ws + c0.y, ws + b0.scale, ws + b0.shift, ws + n->a_pool, ws + n->pool_idx, n->B, n->Hs, n->Ws, 64, st));
-    n->mark(OSI_PROF_BN_FWD, st);
+    OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
     // bottleneck blocks
     for (Block& k : n->blocks) {
         const float* x = ws + k.x_in;
@@ -384,15 +406,14 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
             BN& b = n->bns[c.bn];
             float* xd = ws + n->scratch[0];
             hipStream_t ds_st = st;
-            static const bool fork_fwd = !(getenv("OSI_FWD_FORK") && getenv("OSI_FWD_FORK")[0] == '0');   // dev A/B switch
-            if (fork_fwd && n->async_wgrad()) {
+            if (n->fwd_fork && n->async_wgrad()) {
                 if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
                 if (hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) return OSI_ERR_LAUNCH;
                 ds_st = n->side; forked = true;
             }
             OSI_TRY(conv_bn_fwd(n, k.ds, params, buffers, ws, x, params + c.w_off, training, ds_st, forked ? n->bn_ws2 : n->bn_ws));
             OSI_TRY(osi_bn_apply(ws + c.y, nullptr, ws + b.scale, ws + b.shift, xd, b.M, b.C, 0, ds_st));
-            n->mark(OSI_PROF_BN_FWD, ds_st);
+            OSI_TRY(n->mark(OSI_PROF_BN_FWD, ds_st));
             if (forked && hipEventRecord(n->ev_join, n->side) != hipSuccess) return OSI_ERR_LAUNCH;
             res = xd;
         }
@@ -402,7 +423,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
             OSI_TRY(conv_bn_fwd(n, cs[j], params, buffers, ws, in, params + c.w_off, training, st, n->bn_ws));
             if (j < 2) {
                 OSI_TRY(osi_bn_apply_relu_mask(ws + c.y, nullptr, ws + b.scale, ws + b.shift, ws + c.a, ws + c.mask, b.M, b.C, st));
-                n->mark(OSI_PROF_BN_FWD, st);
+                OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
                 in = ws + c.a;
             }
         }
@@ -410,7 +431,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
         Conv& c3 = n->convs[k.c3];
         BN& b3 = n->bns[c3.bn];
         OSI_TRY(osi_bn_apply_relu_mask(ws + c3.y, res, ws + b3.scale, ws + b3.shift, ws + c3.a, ws + c3.mask, b3.M, b3.C, st));
-        n->mark(OSI_PROF_BN_FWD, st);
+        OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
     }
     // head
     const float* last = ws + n->blocks.back().out;
@@ -428,7 +449,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
         n->fwd_done = true;
         n->next_stage = 0;
     }
-    n->mark(OSI_PROF_OTHER, st);
+    OSI_TRY(n->mark(OSI_PROF_OTHER, st));
     return OSI_OK;
 }
 
@@ -454,7 +475,7 @@ static int wgrad(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const
         n->buf_pending[gi] = true;
         n->side_dirty = true;
     }
-    n->mark(OSI_PROF_CONV_WGRAD, st);
+    OSI_TRY(n->mark(OSI_PROF_CONV_WGRAD, st));
     return OSI_OK;
 }
 
@@ -466,7 +487,7 @@ static int bn_conv_wgrad(osi_resnet50* n, int ci, const float* params, float* gr
     float* g = ws + n->scratch[gi];
     OSI_TRY(osi_bn_backward_relu_mask(g, ws + c.mask, ws + c.y, ws + b.mean, ws + b.invstd, params + b.g_off, g, gmasked,
                                       grads + b.g_off, grads + b.b_off, b.M, b.C, ws + n->bn_ws, n->bn_ws_bytes, st));
-    n->mark(OSI_PROF_BN_BWD, st);
+    OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
     return wgrad(n, ci, grads, ws, gi, conv_in, st);
 }
 
@@ -481,7 +502,7 @@ static int bn_bwd_fused(osi_resnet50* n, int ci, const float* params, float* gra
     OSI_TRY(osi_bn_backward_fused(ws + n->scratch[gi], ws + c.y, ws + b.mean, ws + b.invstd, params + b.g_off, psum_g, psum_gx,
                                   n->fused_P, ws + n->scratch[dyi], grads + b.g_off, grads + b.b_off, b.M, b.C, ws + n->bn_ws,
                                   n->bn_ws_bytes, st));
-    n->mark(OSI_PROF_BN_BWD, st);
+    OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
     return OSI_OK;
 }
 
@@ -505,7 +526,7 @@ static int dgrad_fused(osi_resnet50* n, int ci, const float* params, float* ws, 
     OSI_TRY(osi_conv_dgrad_fused(&c.d, ws + n->scratch[dyi], params + c.w_off, ws + n->scratch[dxi],
                                  addi >= 0 ? ws + n->scratch[addi] : nullptr, &f, OSI_TILE_AUTO, &P, st));
     n->fused_P = P;
-    n->mark(OSI_PROF_CONV_DGRAD, st);
+    OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, st));
     return OSI_OK;
 }
 
@@ -524,54 +545,54 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
         if (has_ds) {
             Conv& cd = n->convs[k.ds];
             int t1 = n->take(st);
-            if (t1 < 0) return OSI_ERR_STATE;
+            if (t1 < 0) return t1;
             OSI_TRY(bn_bwd_fused(n, k.ds, params, grads, ws, go, t1, 1, st));
             OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
             dxbase = n->take(st);
-            if (dxbase < 0) return OSI_ERR_STATE;
+            if (dxbase < 0) return dxbase;
             OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dxbase), 0, OSI_TILE_AUTO, st));
-            n->mark(OSI_PROF_CONV_DGRAD, st);
+            OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, st));
             n->give(t1);
         }
         d3 = n->take(st);
-        if (d3 < 0) return OSI_ERR_STATE;
+        if (d3 < 0) return d3;
         OSI_TRY(bn_bwd_fused(n, k.c3, params, grads, ws, go, d3, 0, st));
         if (has_ds) n->give(go);
         else dxbase = go;          // identity skip: the masked gradient itself continues to the block input
     } else {
         dxbase = n->take(st);
-        if (dxbase < 0) return OSI_ERR_STATE;
+        if (dxbase < 0) return dxbase;
         if (has_ds) {
             Conv& cd = n->convs[k.ds];
             BN& bd = n->bns[cd.bn];
             int t1 = n->take(st);
-            if (t1 < 0) return OSI_ERR_STATE;
+            if (t1 < 0) return t1;
             OSI_TRY(osi_bn_backward_relu_mask(S(go), ws + c3.mask, ws + cd.y, ws + bd.mean, ws + bd.invstd, params + bd.g_off,
                                               S(t1), nullptr, grads + bd.g_off, grads + bd.b_off, bd.M, bd.C, ws + n->bn_ws,
                                               n->bn_ws_bytes, st));
-            n->mark(OSI_PROF_BN_BWD, st);
+            OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
             OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
             OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dxbase), 0, OSI_TILE_AUTO, st));
-            n->mark(OSI_PROF_CONV_DGRAD, st);
+            OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, st));
             n->give(t1);
         }
         BN& b3 = n->bns[c3.bn];
         OSI_TRY(osi_bn_backward_relu_mask(S(go), ws + c3.mask, ws + c3.y, ws + b3.mean, ws + b3.invstd, params + b3.g_off, S(go),
                                           has_ds ? nullptr : S(dxbase), grads + b3.g_off, grads + b3.b_off, b3.M, b3.C,
                                           ws + n->bn_ws, n->bn_ws_bytes, st));
-        n->mark(OSI_PROF_BN_BWD, st);
+        OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
         d3 = go;
     }
     // conv3 -> (mask a2, bn2) -> conv2 -> (mask a1, bn1) -> conv1
     OSI_TRY(wgrad(n, k.c3, grads, ws, d3, ws + c2.a, st));
     int t2 = n->take(st);
-    if (t2 < 0) return OSI_ERR_STATE;
+    if (t2 < 0) return t2;
     OSI_TRY(dgrad_fused(n, k.c3, params, ws, d3, t2, -1, k.c2, -1, st));
     n->give(d3);
     OSI_TRY(bn_bwd_fused(n, k.c2, params, grads, ws, t2, t2, 0, st));
     OSI_TRY(wgrad(n, k.c2, grads, ws, t2, ws + c1.a, st));
     int t3 = n->take(st);
-    if (t3 < 0) return OSI_ERR_STATE;
+    if (t3 < 0) return t3;
     OSI_TRY(dgrad_fused(n, k.c2, params, ws, t2, t3, -1, k.c1, -1, st));
     n->give(t2);
     OSI_TRY(bn_bwd_fused(n, k.c1, params, grads, ws, t3, t3, 0, st));
@@ -580,14 +601,14 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
         // the block input is the previous block's output: fuse that block's final ReLU mask and its bn3 (+ downsample BN) reductions
         Block& pk = n->blocks[bi - 1];
         int dxn = has_ds ? dxbase : n->take(st);   // downsample case: add in place (each lane reads then writes its own element)
-        if (dxn < 0) return OSI_ERR_STATE;
+        if (dxn < 0) return dxn;
         OSI_TRY(dgrad_fused(n, k.c1, params, ws, t3, dxn, dxbase, pk.c3, pk.ds, st));
         if (dxn != dxbase) n->give(dxbase);
         n->cur_grad = dxn;
         n->go_fused = true;
     } else {
         OSI_TRY(osi_conv_dgrad(&c1.d, S(t3), params + c1.w_off, S(dxbase), 1, OSI_TILE_AUTO, st));
-        n->mark(OSI_PROF_CONV_DGRAD, st);
+        OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, st));
         n->cur_grad = dxbase;
         n->go_fused = false;
     }
@@ -604,7 +625,7 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
     float* ws = (float*)workspace;
     auto S = [&](int i) { return ws + n->scratch[i]; };
     if (n->overlap && !n->prof_on) OSI_TRY(n->ensure_side());
-    n->mark(OSI_PROF_START, st);
+    OSI_TRY(n->mark(OSI_PROF_START, st));
 
     for (int stage = stage_lo; stage < stage_hi; ++stage) {
         if (stage == 0) {
@@ -624,8 +645,9 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             OSI_TRY(osi_linear_bwd(dfeat, ws + n->pooled, params + fw.off, ws + n->dpooled, 0, grads + fw.off, grads + fb.off, n->B,
                                    2048, n->F, st));
             int g = n->take(st);
+            if (g < 0) return g;
             OSI_TRY(osi_avgpool_bwd(ws + n->dpooled, S(g), n->B, n->Hf * n->Wf, 2048, st));
-            n->mark(OSI_PROF_OTHER, st);
+            OSI_TRY(n->mark(OSI_PROF_OTHER, st));
             n->cur_grad = g;
             n->go_fused = false;
         }
@@ -639,14 +661,14 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             Conv& c0 = n->convs[0];
             int go = n->cur_grad;
             int t = n->take(st);
-            if (t < 0) return OSI_ERR_STATE;
+            if (t < 0) return t;
             // max-pool scatter + ReLU gate + bn1 backward gathered on the fly from the pooled gradient (no 112x112x64 gradient)
             BN& b0 = n->bns[c0.bn];
             OSI_TRY(osi_bn_relu_maxpool_bwd(S(go), ws + n->pool_idx, ws + c0.y, ws + b0.mean, ws + b0.invstd, params + b0.g_off, S(t),
                                             grads + b0.g_off, grads + b0.b_off, n->B, n->Hs, n->Ws, 64, ws + n->bn_ws, n->bn_ws_bytes, st));
-            n->mark(OSI_PROF_BN_BWD, st);
+            OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
             n->give(go);
-            OSI_TRY(wgrad(n, 0, grads, ws, t, ws + n->x4, st));
+            OSI_TRY(wgrad(n, 0, grads, ws, t, n->x4_cur ? n->x4_cur : ws + n->x4, st));
             n->give(t);
             n->cur_grad = -1;
             n->fwd_done = false;
@@ -662,6 +684,17 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
 int osi_resnet50_set_overlap(osi_resnet50_t n, int enable) {
     OSI_REQUIRE(n);
     n->overlap = enable != 0;
+    return OSI_OK;
+}
+
+int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
+    OSI_REQUIRE(n && name);
+    if (!strcmp(name, "overlap")) n->overlap = value != 0;
+    else if (!strcmp(name, "fwd_fork")) n->fwd_fork = value != 0;
+    else if (!strcmp(name, "side_priority_normal")) {
+        if (n->side) return OSI_ERR_STATE;   // the side stream already exists with the other priority
+        n->side_prio_normal = value != 0;
+    } else return OSI_ERR_ARG;
     return OSI_OK;
 }
 

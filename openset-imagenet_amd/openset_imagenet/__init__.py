@@ -1,11 +1,15 @@
 """openset_imagenet — MI355X-native training hot path with the reference package's interface.
 
-Importable pieces (mirroring the reference package layout): `model.ResNet50`, `losses.EntropicOpensetLoss` / `AverageMeter` /
-`EarlyStopping`, `train.train` / `save_checkpoint` / `load_checkpoint`, `util.NameSpace` / `load_yaml`, `tools.device` ...
+Same import surface as the reference package (openset_imagenet/__init__.py:1-7): `ResNet50`, `ImagenetDataset`, and the
+sub-modules `util`, `train`, `metrics`, `losses`; plus `tools` (the three `vast.tools` symbols the path uses), `dataset`,
+`optim`, `dp`, `pipeline`. `OpenSetProtocol` (protocol.py, offline CSV generation from WordNet / robustness metadata) is out of
+scope for this build and is not exported — see INTEGRATION.md.
 """
 from . import tools, util
+from . import dataset, losses, metrics, train
 from .losses import (AverageMeter, EarlyStopping, EntropicOpensetLoss, GarbageLoss, ObjectosphereLoss, SoftmaxLoss)
 from .model import ResNet50
+from .pipeline import CanvasDataset as ImagenetDataset
 
-__all__ = ["ResNet50", "EntropicOpensetLoss", "SoftmaxLoss", "GarbageLoss", "ObjectosphereLoss", "AverageMeter",
-           "EarlyStopping", "tools", "util"]
+__all__ = ["ResNet50", "ImagenetDataset", "EntropicOpensetLoss", "SoftmaxLoss", "GarbageLoss", "ObjectosphereLoss", "AverageMeter",
+           "EarlyStopping", "tools", "util", "train", "metrics", "losses", "dataset"]

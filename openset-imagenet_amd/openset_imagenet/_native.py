@@ -11,6 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_v
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.path.join(CSRC_DIR, "libosi_hip.so")
+TORCH_LIB_PATH = os.path.join(CSRC_DIR, "libosi_torch.so")   # TORCH_LIBRARY(osi, ...) registration on top of the C ABI
 
 OSI_OK = 0
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64 = 0, 1, 2, 3, 4
@@ -35,6 +36,8 @@ _SIGS = {
     "osi_abi_version": (c_int, []),
     "osi_build_arch": (c_char_p, []),
     "osi_strerror": (c_char_p, [c_int]),
+    "osi_set_tuning": (c_int, [c_char_p, c_int]),
+    "osi_get_tuning": (c_int, [c_char_p, POINTER(c_int)]),
     "osi_conv_fwd": (c_int, [_PD, P, P, P, c_int, P]),
     "osi_conv_fwd_bnstats_workspace": (c_size_t, [_PD]),
     "osi_conv_fwd_bnstats": (c_int, [_PD, P, P, P, c_int, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
@@ -58,7 +61,9 @@ _SIGS = {
     "osi_bn_backward_relu_mask": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
     "osi_nchw3_to_nhwc4": (c_int, [P, P, c_int, c_int, c_int, P]),
     "osi_u8hwc3_to_nhwc4": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "osi_u8_crop_flip_to_nhwc4": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "osi_resnet50_stage_input_u8": (c_int, [c_void_p, P, P, P, P]),
+    "osi_resnet50_bind_input_nhwc4": (c_int, [c_void_p, P]),
     "osi_maxpool3x3s2_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "osi_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "osi_bn_relu_maxpool_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
@@ -70,6 +75,7 @@ _SIGS = {
     "osi_loss_fwd_bwd": (c_int, [c_int, P, P, c_int, c_int, c_float, c_longlong, P, P, c_int, c_float, c_float, P, P, P, P]),
     "osi_softmax": (c_int, [P, P, c_int, c_int, P]),
     "osi_confidence_accumulate": (c_int, [P, P, c_int, c_int, c_float, c_longlong, c_int, P, P]),
+    "osi_confidence_from_scores": (c_int, [P, P, c_int, c_int, c_float, c_longlong, c_int, P, P]),
     "osi_oscr_workspace": (c_size_t, [c_int]),
     "osi_oscr_f32": (c_int, [P, P, c_int, c_int, c_longlong, P, c_size_t, P, P, P, P, P]),
     "osi_oscr_f64": (c_int, [P, P, c_int, c_int, c_longlong, P, c_size_t, P, P, P, P, P]),
@@ -90,6 +96,7 @@ _SIGS = {
     "osi_resnet50_num_stages": (c_int, [c_void_p]),
     "osi_resnet50_stage_grad_range": (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     "osi_resnet50_set_overlap": (c_int, [c_void_p, c_int]),
+    "osi_resnet50_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "osi_resnet50_profile": (c_int, [c_void_p, c_int]),
     "osi_resnet50_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int)]),
     "osi_resnet50_forward": (c_int, [c_void_p, P, P, P, P, P, P, P, c_int, P]),
@@ -117,7 +124,29 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = handle
+        # development A/B switches: the environment is read HERE, once, and handed to the library explicitly
+        for env, knob in (("OSI_WGRAD_TILE", b"wgrad_tile"), ("OSI_WGRAD_BLOCKS", b"wgrad_blocks"), ("OSI_WGRAD_NST", b"wgrad_nst"),
+                          ("OSI_WGRAD_GROUP", b"wgrad_group"), ("OSI_BN_GRID", b"bn_grid")):
+            if os.environ.get(env):
+                check(handle.osi_set_tuning(knob, int(os.environ[env])), f"osi_set_tuning({knob.decode()})")
     return _lib
+
+
+_ops = None
+
+
+def ops():
+    """`torch.ops.osi` — the PyTorch-ROCm custom ops the Python package calls on the hot path (csrc/osi_torch_ops.cpp). Loading the
+    registration library also loads libosi_hip.so (rpath $ORIGIN); raises NativeLibraryMissing when it has not been built."""
+    global _ops
+    if _ops is None:
+        lib()   # the C-ABI library first: same handle for ctypes and for the op library, and the loud failure if it is missing
+        if not os.path.isfile(TORCH_LIB_PATH):
+            raise NativeLibraryMissing(f"{TORCH_LIB_PATH} not found: build it first (python __graft_entry__.py, or make -C {CSRC_DIR}).")
+        import torch
+        torch.ops.load_library(TORCH_LIB_PATH)
+        _ops = torch.ops.osi
+    return _ops
 
 
 def declared_symbols():

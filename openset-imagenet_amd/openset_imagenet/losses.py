@@ -30,19 +30,12 @@ class _FusedLoss(torch.autograd.Function):
             raise TypeError("target must be int64")
         logits_c = logits.contiguous().float()
         target_c = target.contiguous()
-        B, C = logits_c.shape
-        loss = torch.empty((), device=logits.device, dtype=torch.float32)
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
-        dlogits = torch.empty_like(logits_c) if need_grad else None
-        feats_c = dfeat = None
-        Fdim = 0
-        if features is not None:
-            feats_c = features.contiguous().float()
-            Fdim = feats_c.shape[1]
-            dfeat = torch.empty_like(feats_c)
-        N.check(N.lib().osi_loss_fwd_bwd(mode, N.ptr(logits_c), N.ptr(target_c), B, C, float(unk_w), int(ignore_index),
-                                         N.ptr(class_w), N.ptr(feats_c), Fdim, float(xi), float(alpha), N.ptr(loss),
-                                         N.ptr(dlogits), N.ptr(dfeat), N.stream_of(logits_c)), "osi_loss_fwd_bwd")
+        feats_c = None if features is None else features.contiguous().float()
+        loss, dlogits, dfeat = N.ops().loss_fwd_bwd(mode, logits_c, target_c, float(unk_w), int(ignore_index), class_w, feats_c,
+                                                    float(xi), float(alpha), bool(need_grad))
+        dlogits = dlogits if need_grad else None
+        dfeat = dfeat if features is not None else None
         ctx.save_for_backward(dlogits if dlogits is not None else loss.new_empty(0),
                               dfeat if dfeat is not None else loss.new_empty(0))
         ctx.has_feat = features is not None
@@ -110,10 +103,7 @@ class ObjectosphereLoss:
 def softmax(logits):
     """Row softmax on the GPU (validation path, reference train.py:177)."""
     N.require_gpu_f32(logits)
-    x = logits.contiguous().float()
-    out = torch.empty_like(x)
-    N.check(N.lib().osi_softmax(N.ptr(x), N.ptr(out), x.shape[0], x.shape[1], N.stream_of(x)), "osi_softmax")
-    return out
+    return N.ops().softmax(logits.contiguous().float())
 
 
 class AverageMeter:

@@ -39,8 +39,13 @@ class _Net:
         self.h = ctypes.c_void_p()
         N.check(N.lib().osi_resnet50_create(ctypes.byref(self.h), B, H, W, F, O, int(bool(logit_bias))), "osi_resnet50_create")
         self.ws_bytes = N.lib().osi_resnet50_workspace_bytes(self.h)
-        if os.environ.get("OSI_NO_OVERLAP"):  # A/B switch: keep the weight-gradient kernels on the main stream
-            N.check(N.lib().osi_resnet50_set_overlap(self.h, 0))
+        # development A/B switches (environment read here, handed to the executor explicitly)
+        if os.environ.get("OSI_NO_OVERLAP"):     # keep the weight-gradient kernels on the main stream
+            N.check(N.lib().osi_resnet50_set_option(self.h, b"overlap", 0))
+        if os.environ.get("OSI_FWD_FORK") == "0":
+            N.check(N.lib().osi_resnet50_set_option(self.h, b"fwd_fork", 0))
+        if os.environ.get("OSI_SIDE_PRIO", "")[:1] == "n":
+            N.check(N.lib().osi_resnet50_set_option(self.h, b"side_priority_normal", 1))
 
     def __del__(self):
         try:
@@ -58,10 +63,15 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, image, anchor, model, flip):
         ctx.model = model
         ctx.set_materialize_grads(False)
-        return model._run_forward(image, True, flip)
+        out = model._run_forward(image, True, flip)
+        ctx.serial = model._fwd_serial
+        return out
 
     @staticmethod
     def backward(ctx, dlogits, dfeatures):
+        if ctx.serial != ctx.model._fwd_serial:
+            raise RuntimeError("backward() of a forward pass that is no longer the model's latest one: the executor keeps the "
+                               "activations of ONE forward (the reference loop is forward, loss, backward, step — train.py:132-139)")
         ctx.model._run_backward(dlogits, dfeatures)
         return None, None, None, None
 
@@ -123,6 +133,8 @@ class ResNet50(nn.Module):
         self._nets = {}
         self._ws = None
         self._grad_sync = None   # set by dp.DistributedDataParallel
+        self._fwd_serial = 0     # number of forward passes run; a backward must belong to the latest one
+        self._grads_fresh = False  # a backward has filled the gradient arena since the last optimizer.zero_grad()
         self.reset_parameters()
 
     # ------------------------------------------------------------------------------------------------------
@@ -216,10 +228,21 @@ class ResNet50(nn.Module):
             self._ws = torch.empty(net.ws_bytes, dtype=torch.uint8, device=dev)
         return net
 
+    def mark_gradients_ready(self):
+        """Tell the fused optimizers that the gradient arena was filled by hand (tests, custom loops) rather than by backward()."""
+        self._grads_fresh = True
+
+    @staticmethod
+    def _is_nhwc4(image):
+        """fp32 [B, H, W, 4] batch already in the executor's input layout (written by pipeline.DevicePrefetcher)."""
+        return image.dtype == torch.float32 and image.dim() == 4 and image.shape[3] == 4 and image.shape[1] != 3
+
     def _check_image(self, image):
         if isinstance(image, torch.Tensor) and image.dtype == torch.uint8:   # decoded RGB batch, staged on the device
             if image.dim() != 4 or image.shape[3] != 3:
                 raise ValueError("a uint8 image batch must be [B, H, W, 3] (decoded RGB rows)")
+        elif isinstance(image, torch.Tensor) and self._is_nhwc4(image):
+            pass
         elif not isinstance(image, torch.Tensor) or image.dim() != 4 or image.shape[1] != 3:
             raise ValueError("expected an image batch [B, 3, H, W]")
         if not image.is_cuda or not self._flat_params.is_cuda:
@@ -233,55 +256,52 @@ class ResNet50(nn.Module):
     def _run_forward(self, image, want_grad, flip=None):
         image = image.contiguous()
         staged = image.dtype == torch.uint8
-        if staged:
+        bound = not staged and self._is_nhwc4(image)
+        if staged or bound:
             B, H, W, _ = image.shape
         else:
             B, _, H, W = image.shape
         net = self._net(B, H, W)
-        logits = torch.empty(B, self._O, device=image.device)
-        features = torch.empty(B, self._F, device=image.device)
-        if staged:   # ToTensor + horizontal flip + NHWC4 staging in one pass on the device (osi_u8hwc3_to_nhwc4)
-            if flip is not None:
-                flip = torch.as_tensor(flip).to(device=image.device, dtype=torch.uint8).contiguous()
-                if flip.numel() != B:
-                    raise ValueError("flip must hold one flag per image")
-            N.check(N.lib().osi_resnet50_stage_input_u8(net.h, N.ptr(image), N.ptr(flip), N.ptr(self._ws), N.stream_of(image)),
-                    "osi_resnet50_stage_input_u8")
+        if staged and flip is not None:   # ToTensor + horizontal flip + NHWC4 staging in one pass on the device (osi_u8hwc3_to_nhwc4)
+            flip = torch.as_tensor(flip).to(device=image.device, dtype=torch.uint8).contiguous()
+            if flip.numel() != B:
+                raise ValueError("flip must hold one flag per image")
         elif flip is not None:
             raise ValueError("flip flags are only meaningful with a uint8 [B,H,W,3] batch")
-        N.check(N.lib().osi_resnet50_forward(net.h, N.ptr(self._flat_params), N.ptr(self._flat_buffers), N.ptr(self._nbt),
-                                             None if staged else N.ptr(image), N.ptr(self._ws), N.ptr(logits), N.ptr(features),
-                                             1 if self.training else 0, N.stream_of(image)), "osi_resnet50_forward")
-        self._last = (net, image if want_grad else None)
+        # one custom op = the whole network on the current HIP stream: uint8 batches are staged, NHWC4 batches bound in place
+        # (conv1 forward now, conv1 weight gradient at the end of this step's backward), NCHW batches converted on the way in
+        logits, features = N.ops().resnet50_forward(net.h.value, self._flat_params, self._flat_buffers, self._nbt, image, flip,
+                                                    self._ws, self._F, self._O, bool(self.training))
+        self._fwd_serial += 1
+        self._last = (net, image if (want_grad or bound) else None)   # keeps a bound batch alive until the next forward
         return logits, features
 
     def _run_backward(self, dlogits, dfeatures):
         net, _ = self._last
-        lib = N.lib()
         if dlogits is None:
             dlogits = torch.zeros(net_shape(self, net)[0], self._O, device=self._flat_params.device)
         dlogits = dlogits.contiguous().float()
         dfeatures = None if dfeatures is None else dfeatures.contiguous().float()
-        st = N.stream_of(dlogits)
         sync = self._grad_sync
+        bwd = N.ops().resnet50_backward
         if sync is None:  # single GPU: all stages in one call (one side-stream join at the end)
-            N.check(lib.osi_resnet50_backward(net.h, N.ptr(self._flat_params), N.ptr(self._flat_grads), N.ptr(self._ws),
-                                              N.ptr(dlogits), N.ptr(dfeatures), 0, self._n_stages, st), "osi_resnet50_backward")
+            bwd(net.h.value, self._flat_params, self._flat_grads, self._ws, dlogits, dfeatures, 0, self._n_stages)
         else:             # data parallel: stage by stage, each finished slice of the gradient arena goes to the all-reduce
             for s in range(self._n_stages):
-                N.check(lib.osi_resnet50_backward(net.h, N.ptr(self._flat_params), N.ptr(self._flat_grads), N.ptr(self._ws),
-                                                  N.ptr(dlogits), N.ptr(dfeatures), s, s + 1, st), "osi_resnet50_backward")
+                bwd(net.h.value, self._flat_params, self._flat_grads, self._ws, dlogits, dfeatures, s, s + 1)
                 lo, hi = self._stage_ranges[s]
                 sync.bucket_ready(self._flat_grads, lo, hi)
             sync.finish()
+        self._grads_fresh = True
         self.bind_gradients()
 
     def forward(self, image, flip=None):
         """Forward pass: returns (logits, deep features) like the reference (model.py:28-39).
 
         `image` is the reference's fp32 [B,3,H,W] batch in [0,1], or — the device-side input pipeline — a uint8 [B,H,W,3] batch
-        of decoded, cropped RGB rows with optional per-image horizontal-flip flags: ToTensor(), RandomHorizontalFlip and the
-        layout staging then happen in one pass on the GPU and the host link carries a quarter of the bytes."""
+        of decoded, cropped RGB rows with optional per-image horizontal-flip flags (ToTensor(), RandomHorizontalFlip and the
+        layout staging then happen in one pass on the GPU and the host link carries a quarter of the bytes), or an fp32
+        [B,H,W,4] batch already staged in the executor's layout by pipeline.DevicePrefetcher (read in place)."""
         self._check_image(image)
         if torch.is_grad_enabled() and self.training and self._plist[0].requires_grad:
             return _BackboneFn.apply(image, self._anchor, self, flip)

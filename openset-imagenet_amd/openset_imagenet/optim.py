@@ -25,6 +25,7 @@ def _arena_of(params):
 
 class _FlatOptimizer(torch.optim.Optimizer):
     _state_names = ()
+    _has_step = True    # per-parameter "step" entry in the state dict (torch.optim.Adam has one, torch.optim.SGD does not)
 
     def __init__(self, model_or_params, defaults):
         if isinstance(model_or_params, torch.nn.Module):
@@ -40,6 +41,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self._model = model
         self._flat_state = {}
         self._steps = 0
+        self._loaded_state = False   # load_state_dict brought moment / momentum buffers along
 
     def _ensure_state(self):
         m = self._model
@@ -59,13 +61,23 @@ class _FlatOptimizer(torch.optim.Optimizer):
         m = self._model
         for (name, off, numel, shape), p in zip(m._pinfo, m._plist):
             st = self.state[p]
-            st["step"] = torch.tensor(float(self._steps))
+            if self._has_step:
+                st["step"] = torch.tensor(float(self._steps))
             for k in self._state_names:
                 st[k] = m._view(self._flat_state[k], off, numel, shape)
 
     def zero_grad(self, set_to_none=True):
         # the executor overwrites the whole gradient arena each backward; dropping the references is enough
         super().zero_grad(set_to_none=set_to_none)
+        self._model._grads_fresh = False
+
+    def _skip_step(self):
+        """torch skips parameters whose .grad is None; here the arena is all-or-nothing: without a backward since the last
+        zero_grad() there is nothing to apply (stepping would re-apply stale gradients)."""
+        m = self._model
+        if any(not p.requires_grad for p in m._plist):
+            raise RuntimeError("the fused optimizers step the whole arena: frozen (requires_grad=False) parameters are not supported")
+        return not getattr(m, "_grads_fresh", False)
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -82,6 +94,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 if k in st and st[k] is not None:
                     m._view(self._flat_state[k], off, numel, shape).copy_(st[k])
         self._steps = steps
+        self._loaded_state = any(k in self.state.get(p, {}) and self.state[p][k] is not None
+                                 for p in m._plist for k in self._state_names)
         self._bind_views()
 
 
@@ -96,14 +110,14 @@ class Adam(_FlatOptimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         m = self._model
+        if self._skip_step():
+            return
         self._ensure_state()
         g = self.param_groups[0]
         self._steps += 1
         p, gr = m.flat_parameters(), m.flat_gradients()
-        N.check(N.lib().osi_adam_step(N.ptr(p), N.ptr(gr), N.ptr(self._flat_state["exp_avg"]),
-                                      N.ptr(self._flat_state["exp_avg_sq"]), p.numel(), float(g["lr"]), float(g["betas"][0]),
-                                      float(g["betas"][1]), float(g["eps"]), self._steps, float(grad_scale), N.stream_of(p)),
-                "osi_adam_step")
+        N.ops().adam_step(p, gr, self._flat_state["exp_avg"], self._flat_state["exp_avg_sq"], float(g["lr"]), float(g["betas"][0]),
+                          float(g["betas"][1]), float(g["eps"]), self._steps, float(grad_scale))
 
     def state_dict(self):
         for q in self._model._plist:  # materialise torch's per-parameter step counters only when somebody looks
@@ -115,6 +129,7 @@ class Adam(_FlatOptimizer):
 class SGD(_FlatOptimizer):
     """torch.optim.SGD(lr, momentum) (dampening 0, no nesterov, no weight decay) as one fused launch."""
     _state_names = ("momentum_buffer",)
+    _has_step = False
 
     def __init__(self, params, lr=1e-3, momentum=0.9):
         super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=0, nesterov=False, maximize=False,
@@ -123,11 +138,13 @@ class SGD(_FlatOptimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         m = self._model
+        if self._skip_step():
+            return
         self._ensure_state()
         g = self.param_groups[0]
-        first = 1 if self._steps == 0 else 0
+        # torch initialises momentum_buffer = grad on the first step of a FRESH optimizer; a buffer that came in through
+        # load_state_dict (own or stock torch.optim.SGD checkpoint, which carries no step counter) continues as mu*buf + g
+        first = 1 if (self._steps == 0 and not self._loaded_state) else 0
         self._steps += 1
         p, gr = m.flat_parameters(), m.flat_gradients()
-        N.check(N.lib().osi_sgd_step(N.ptr(p), N.ptr(gr), N.ptr(self._flat_state["momentum_buffer"]), p.numel(),
-                                     float(g["lr"]), float(g["momentum"]), first, float(grad_scale), N.stream_of(p)),
-                "osi_sgd_step")
+        N.ops().sgd_step(p, gr, self._flat_state["momentum_buffer"], float(g["lr"]), float(g["momentum"]), bool(first), float(grad_scale))

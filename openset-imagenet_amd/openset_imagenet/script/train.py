@@ -1,9 +1,16 @@
 """train_imagenet.py — command line of the reference (openset_imagenet/script/train.py:8-63): `configuration protocol
 [-o DIR] [-g [IDX]] [--nice N]`. One fix over the reference: `-g 0` / bare `-g` selects GPU 0 (the reference tests `if args.gpu:`,
-which is false for index 0, script/train.py:58). `--synthetic N` (new) trains on N synthetic samples instead of the protocol CSVs."""
+which is false for index 0, script/train.py:58). `--synthetic N` (new) trains on N synthetic samples instead of the protocol CSVs.
+
+Data parallel: started under `python -m torch.distributed.run` (RANK / WORLD_SIZE / LOCAL_RANK in the environment) every rank
+simply runs worker(); with `dist.distributed: on` in the configuration (config/train.yaml, the reference's unused `dist:` block)
+and no such environment, this process becomes the launcher: it starts `dist.gpus` child ranks of the same command line on
+127.0.0.1:`dist.port` BEFORE anything touches the GPU, waits for them and returns rank 0's exit status."""
 import argparse
 import os
 import pathlib
+import subprocess
+import sys
 
 from .. import train as _train
 from .. import util
@@ -22,9 +29,26 @@ def get_args(command_line_options=None):
     return args
 
 
+def _launch_ranks(config, argv):
+    """Start config.dist.gpus ranks of this command line (one per GPU) and wait; no GPU call has happened in this process."""
+    n = int(config.dist.gpus)
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(config.dist.port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-m", "openset_imagenet.script.train", *argv], env=env))
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        raise SystemExit(f"data-parallel ranks exited with {codes}")
+    return 0
+
+
 def main(command_line_options=None):
     args = get_args(command_line_options)
     config = util.load_yaml(args.configuration)
+    dcfg = getattr(config, "dist", None)
+    if dcfg is not None and getattr(dcfg, "distributed", False) and int(getattr(dcfg, "gpus", 1) or 1) > 1 and "RANK" not in os.environ:
+        return _launch_ranks(config, list(sys.argv[1:] if command_line_options is None else command_line_options))
     if args.gpu is not None:
         config.gpu = args.gpu
     config.protocol = args.protocol

@@ -29,5 +29,8 @@ def get_device():
 
 
 def device(x):
-    """Move a tensor or module to the global device (identity when already there)."""
+    """Move a tensor or module to the global device (identity when already there). Tensors in pinned host memory (DataLoader
+    pin_memory=True, reference train.py:304) are copied asynchronously on the current stream: no host synchronisation."""
+    if isinstance(x, torch.Tensor):
+        return x.to(_device, non_blocking=True)
     return x.to(_device)

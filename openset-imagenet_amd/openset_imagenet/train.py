@@ -149,10 +149,8 @@ def validate(model, data_loader, loss_fn, n_classes, trackers, cfg):
             counts.append(labels.shape[0])
             if acc is None:
                 acc = torch.zeros(4, dtype=torch.float64, device=logits.device)
-            lg = logits.contiguous()
-            N.check(N.lib().osi_confidence_accumulate(N.ptr(lg), N.ptr(labels), lg.shape[0], lg.shape[1], float(min_unk_score),
-                                                      int(unknown_class), int(last_valid), N.ptr(acc), N.stream_of(lg)),
-                    "osi_confidence_accumulate")
+            N.ops().confidence_accumulate(logits.contiguous(), labels.contiguous(), float(min_unk_score), int(unknown_class),
+                                          int(last_valid), acc)
     if not losses:
         return
     for value, n in zip(torch.stack(losses).cpu().tolist(), counts):
@@ -182,48 +180,24 @@ def get_arrays(model, loader):
 
 
 def _image_loader(csv_file, imagenet_path, train, loss_type, uint8=True):
-    """ImagenetDataset of the reference (dataset.py:10-54) with its transforms (train.py:259-268), PIL + torch only
-    (torchvision is not a dependency of this build). Decode, Resize(256), crop and flip stay on the host workers; with
-    `uint8` (default) the sample is handed over as the uint8 [224,224,3] crop and ToTensor() runs on the GPU inside the model's
-    input staging (osi_u8hwc3_to_nhwc4): a quarter of the pinned-memory and host-link bytes, no fp32 work on the CPU."""
-    import pandas as pd
-    from PIL import Image
-    from .dataset import LabelTable
+    """ImagenetDataset of the reference (dataset.py:10-54) with its transforms (train.py:259-268) — see pipeline.CanvasDataset:
+    the host workers decode and Resize(256); crop, flip, ToTensor and the layout staging run on the GPU (`uint8`, default), or the
+    reference's own fp32 CHW samples are produced on the host (`uint8=False`)."""
+    from .pipeline import CanvasDataset
+    return CanvasDataset(csv_file, imagenet_path, train, loss_type, uint8)
 
-    class _DS(torch.utils.data.Dataset):
-        def __init__(self):
-            self.frame = pd.read_csv(csv_file, header=None)
-            self.table = LabelTable(self.frame[1].to_numpy())
-            if loss_type == "garbage":
-                self.table.replace_negative_label()
-                self.frame[1] = self.table.labels
-            elif loss_type == "softmax" and train:
-                self.frame = self.frame[self.frame[1] >= 0].reset_index(drop=True)
-                self.table.remove_negative_label()
-            self.root = pathlib.Path(imagenet_path)
 
-        def __len__(self):
-            return len(self.frame)
+def dist_env():
+    """(rank, world, local_rank) of a process started by `python -m torch.distributed.run` (or by the CLI's own launcher,
+    script/train.py) — (0, 1, None) otherwise. The reference never initialises a process group (its `dist:` block is unused,
+    config/train.yaml:35-39); this is what the block was for: one process per GPU, batch_size per GPU (train.yaml:18)."""
+    import os
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        return int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+    return 0, 1, None
 
-        def __getitem__(self, i):
-            path, label = self.frame.iloc[i]
-            img = Image.open(self.root / path).convert("RGB")
-            w, h = img.size
-            s = 256 / min(w, h)
-            img = img.resize((max(256, round(w * s)), max(256, round(h * s))), Image.BILINEAR)     # Resize(256)
-            w, h = img.size
-            if train:                                                                          # RandomCrop(224) + flip(0.5)
-                x0, y0 = random.randint(0, w - 224), random.randint(0, h - 224)
-            else:                                                                              # CenterCrop(224)
-                x0, y0 = (w - 224) // 2, (h - 224) // 2
-            img = img.crop((x0, y0, x0 + 224, y0 + 224))
-            if train and random.random() < 0.5:
-                img = img.transpose(Image.FLIP_LEFT_RIGHT)
-            x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
-            if not uint8:
-                x = x.permute(2, 0, 1).float().div_(255.0)                                      # ToTensor() on the host
-            return x, torch.as_tensor(int(label), dtype=torch.int64)
-    return _DS()
+
+_last_worker_state = {}   # introspection for tests: the objects of the most recent worker() call in this process
 
 
 def worker(cfg):
@@ -231,21 +205,58 @@ def worker(cfg):
     (train.py:237-482) reduced to what drives the hot path. Same cfg keys (config/train.yaml), same checkpoint files
     `{name}_curr.pth` / `{name}_best.pth`, same best-score rule (conf_kn + conf_unk) and early stopping. Logging goes to the
     `logging` module and a CSV of per-epoch scalars (loguru / TensorBoard are not dependencies of this build).
+
+    Data parallel (new; the reference only left vestiges, train.py:10,49-50,79-87,248): under `torch.distributed.run` (or the
+    CLI launcher driven by the `dist:` block) every rank runs this function on its own GPU (LOCAL_RANK), the training set is
+    sharded with a DistributedSampler, the model is wrapped in dp.DistributedDataParallel (bucketed RCCL gradient all-reduce
+    overlapped with backward), `batch_size` is per GPU (train.yaml:18), and only rank 0 validates, logs and writes checkpoints
+    ("Log only on first process. Validate only on first process.", train.py:248).
+
     `cfg.data.synthetic` (new key, default absent) = number of synthetic training samples to use instead of the CSV files."""
     import logging
     import time
+    import torch.distributed as dist
     from .dataset import LabelTable, SyntheticImagenet
+    from .pipeline import DevicePrefetcher
     set_seeds(cfg.seed)
+    rank, world, local_rank = dist_env()
+    distributed = world > 1
     out_dir = pathlib.Path(cfg.output_directory)
     out_dir.mkdir(parents=True, exist_ok=True)
-    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(levelname)s: %(message)s",
-                        handlers=[logging.StreamHandler(), logging.FileHandler(out_dir / cfg.log_name, mode="w")], force=True)
+    handlers = [logging.StreamHandler()]
+    if rank == 0:
+        handlers.append(logging.FileHandler(out_dir / cfg.log_name, mode="w"))
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING,
+                        format="%(asctime)s %(name)s %(levelname)s: %(message)s", handlers=handlers, force=True)
     log = logging.getLogger("openset_imagenet")
-    if cfg.gpu is not None:
+    dcfg = getattr(cfg, "dist", None)
+    backend = getattr(dcfg, "backend", None) or "nccl"
+    if distributed:
+        # one process per GPU: the launcher started us before any GPU call; LOCAL_RANK picks the device (several ranks may share
+        # a device only over gloo, which is how the one-GPU test box rehearses this path)
+        n_dev = max(1, torch.cuda.device_count())
+        index = local_rank % n_dev if backend != "nccl" else local_rank
+        dev = tools.set_device_gpu(index=index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    elif cfg.gpu is not None:
         tools.set_device_gpu(index=cfg.gpu)
     else:
         raise RuntimeError("No GPU device selected: the MI355X build has no CPU training path (pass -g [index])")
+    try:
+        return _worker_body(cfg, log, out_dir, rank, world, distributed)
+    finally:
+        if distributed and dist.is_initialized():
+            dist.destroy_process_group()
 
+
+def _worker_body(cfg, log, out_dir, rank, world, distributed):
+    import time
+    import torch.distributed as dist
+    from .dataset import LabelTable, SyntheticImagenet
+    from .pipeline import DevicePrefetcher
     n_syn = getattr(cfg.data, "synthetic", None)
     if n_syn:
         n_known = {1: 116, 2: 30, 3: 151}[int(cfg.protocol)]
@@ -273,14 +284,19 @@ def worker(cfg):
         train_ds = _image_loader(train_file, cfg.data.imagenet_path, True, cfg.loss.type, u8)
         val_ds = _image_loader(val_file, cfg.data.imagenet_path, False, cfg.loss.type, u8)
         train_table = train_ds.table
-    train_loader = torch.utils.data.DataLoader(train_ds, batch_size=cfg.batch_size, shuffle=True, num_workers=cfg.workers, pin_memory=True)
-    val_loader = torch.utils.data.DataLoader(val_ds, batch_size=cfg.batch_size, num_workers=cfg.workers, pin_memory=True)
+    # loaders (train.py:299-311). batch_size is per GPU; under data parallel every rank draws its own shard of each epoch
+    sampler = torch.utils.data.distributed.DistributedSampler(train_ds, num_replicas=world, rank=rank, shuffle=True, seed=cfg.seed) \
+        if distributed else None
+    lkw = dict(batch_size=cfg.batch_size, num_workers=cfg.workers, pin_memory=True)
+    if cfg.workers > 0:
+        lkw.update(persistent_workers=True, prefetch_factor=4)
+    train_loader = torch.utils.data.DataLoader(train_ds, shuffle=sampler is None, sampler=sampler, **lkw)
+    val_loader = torch.utils.data.DataLoader(val_ds, **lkw)
+    if bool(getattr(cfg.data, "prefetch", True)):      # new key: copy-stream prefetch + device-side crop / flip / ToTensor
+        train_loader, val_loader = DevicePrefetcher(train_loader), DevicePrefetcher(val_loader)
 
-    # number of classes / loss (train.py:329-347)
-    if cfg.loss.type == "entropic":
-        n_classes = train_table.label_count - 1 if train_table.has_negatives() else train_table.label_count
-    else:
-        n_classes = train_table.label_count
+    # number of classes / loss (train.py:329-347): entropic has no output for the unknown label
+    n_classes = train_table.label_count - 1 if cfg.loss.type == "entropic" else train_table.label_count
     class_weights = train_table.calculate_class_weights() if cfg.loss.type == "garbage" else None
     loss_fn = build_loss(cfg, n_classes, class_weights)
     model = build_model(cfg, n_classes)
@@ -289,36 +305,54 @@ def worker(cfg):
 
     best_score, start_epoch = 0.0, 0
     if cfg.checkpoint is not None:
-        if cfg.train_mode == "finetune":
-            load_checkpoint(model, cfg.checkpoint)
+        if cfg.train_mode == "finetune":     # weights only; keeps the checkpoint's epoch, resets the best score (train.py:374-380)
+            start_epoch, _ = load_checkpoint(model, cfg.checkpoint)
         else:
             start_epoch, best_score = load_checkpoint(model, cfg.checkpoint, opt, scheduler)
         log.info(f"Loaded {cfg.checkpoint} at epoch {start_epoch}")
+    net = _dp.DistributedDataParallel(model) if distributed else model   # broadcasts rank 0's parameters and BN buffers
+    _last_worker_state.clear()
+    _last_worker_state.update(model=model, optimizer=opt, rank=rank, world=world, checkpoints_written=0)
     t_metrics = {"j": _losses.AverageMeter()}
     v_metrics = {"j": _losses.AverageMeter(), "conf_kn": _losses.AverageMeter(), "conf_unk": _losses.AverageMeter()}
     early = _losses.EarlyStopping(patience=cfg.patience) if cfg.patience > 0 else None
-    scalars = open(out_dir / f"scalars-{cfg.log_name}.csv", "w")
-    scalars.write("epoch,train/loss,val/loss,val/conf_kn,val/conf_unk\n")
-    log.info(f"Training: protocol {cfg.protocol}, loss {cfg.loss.type}, {n_classes} classes, {len(train_ds)} / {len(val_ds)} samples")
+    scalars = None
+    if rank == 0:
+        scalars = open(out_dir / f"scalars-{cfg.log_name}.csv", "w")
+        scalars.write("epoch,train/loss,val/loss,val/conf_kn,val/conf_unk\n")
+    log.info(f"Training: protocol {cfg.protocol}, loss {cfg.loss.type}, {n_classes} classes, {len(train_ds)} / {len(val_ds)} samples, "
+             f"{world} GPU(s) x batch {cfg.batch_size}")
     for epoch in range(start_epoch, cfg.epochs):
         t0 = time.time()
-        train(model, train_loader, opt, loss_fn, t_metrics, cfg)
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        train(net, train_loader, opt, loss_fn, t_metrics, cfg)
         t1 = time.time()
-        validate(model, val_loader, loss_fn, n_classes, v_metrics, cfg)
-        curr_score = v_metrics["conf_kn"].avg + v_metrics["conf_unk"].avg
+        stop = False
+        if rank == 0:                                     # validate / log / checkpoint on the first process only
+            validate(model, val_loader, loss_fn, n_classes, v_metrics, cfg)
+            curr_score = v_metrics["conf_kn"].avg + v_metrics["conf_unk"].avg
+            scalars.write(f"{epoch},{t_metrics['j'].avg},{v_metrics['j'].avg},{v_metrics['conf_kn'].avg},{v_metrics['conf_unk'].avg}\n")
+            scalars.flush()
+            log.info(f"ep:{epoch} train:{t_metrics} val:{v_metrics} t:{t1 - t0:.1f}s v:{time.time() - t1:.1f}s")
+            save_checkpoint(out_dir / (cfg.name + "_curr.pth"), model, epoch, opt, curr_score, scheduler)
+            _last_worker_state["checkpoints_written"] += 1
+            if curr_score > best_score:
+                best_score = curr_score
+                save_checkpoint(out_dir / (cfg.name + "_best.pth"), model, epoch, opt, best_score, scheduler)
+                _last_worker_state["checkpoints_written"] += 1
+            if early is not None:
+                early(metrics=curr_score, loss=False)
+                stop = early.early_stop
         if scheduler is not None:
             scheduler.step()
-        scalars.write(f"{epoch},{t_metrics['j'].avg},{v_metrics['j'].avg},{v_metrics['conf_kn'].avg},{v_metrics['conf_unk'].avg}\n")
-        scalars.flush()
-        log.info(f"ep:{epoch} train:{t_metrics} val:{v_metrics} t:{t1 - t0:.1f}s v:{time.time() - t1:.1f}s")
-        save_checkpoint(out_dir / (cfg.name + "_curr.pth"), model, epoch, opt, curr_score, scheduler)
-        if curr_score > best_score:
-            best_score = curr_score
-            save_checkpoint(out_dir / (cfg.name + "_best.pth"), model, epoch, opt, best_score, scheduler)
-        if early is not None:
-            early(metrics=curr_score, loss=False)
-            if early.early_stop:
-                log.info("early stop")
-                break
-    scalars.close()
+        if distributed:                                   # every rank follows rank 0's early-stopping decision
+            flag = [stop, best_score]
+            dist.broadcast_object_list(flag, src=0)
+            stop, best_score = flag
+        if stop:
+            log.info("early stop")
+            break
+    if scalars is not None:
+        scalars.close()
     return best_score

@@ -124,3 +124,118 @@ def test_cli_arguments_and_label_table():
     x, y = ds[1]
     assert x.shape == (3, 32, 32) and x.dtype == torch.float32 and 0 <= float(x.min()) and float(x.max()) < 1 and int(y) == -1
     assert torch.equal(ds[1][0], x)
+
+
+def test_package_surface_matches_the_reference_init():
+    """The reference's openset_imagenet/__init__.py:1-7 exports ImagenetDataset, ResNet50 and the sub-modules util, train,
+    metrics, losses (OpenSetProtocol is out of scope and documented as such)."""
+    for name in ("ResNet50", "ImagenetDataset", "util", "train", "metrics", "losses"):
+        assert hasattr(oi, name), name
+    assert callable(oi.train.load_checkpoint) and callable(oi.train.worker) and callable(oi.metrics.confidence)
+    assert callable(oi.metrics.predict_objectosphere) and callable(oi.losses.EntropicOpensetLoss)
+    with pytest.raises(RuntimeError):                       # the metric kernels need the GPU too
+        oi.metrics.confidence(torch.rand(2, 3), torch.tensor([0, -1]))
+
+
+def test_torch_op_library_registers_without_a_gpu():
+    """libosi_torch.so (TORCH_LIBRARY(osi, ...)) loads on a CPU-only host and registers every hot-path op; CPU tensors find no
+    kernel (the ops are registered for the HIP device key only) — no compute happens here."""
+    from openset_imagenet import _native as N
+    ops = N.ops()
+    for name in ("resnet50_forward", "resnet50_backward", "loss_fwd_bwd", "adam_step", "sgd_step", "stage_canvas", "softmax",
+                 "confidence_accumulate"):
+        assert hasattr(ops, name), name
+    with pytest.raises(NotImplementedError):
+        ops.softmax(torch.zeros(2, 3))
+    assert N.lib().osi_abi_version() >= 2
+
+
+def test_tuning_knobs_are_explicit():
+    """Development switches travel through osi_set_tuning / osi_resnet50_set_option, not through getenv inside launch functions."""
+    import ctypes
+    from openset_imagenet import _native as N
+    lib = N.lib()
+    v = ctypes.c_int()
+    assert lib.osi_get_tuning(b"wgrad_blocks", ctypes.byref(v)) == 0 and v.value == 2048
+    assert lib.osi_set_tuning(b"wgrad_blocks", 1024) == 0 and lib.osi_get_tuning(b"wgrad_blocks", ctypes.byref(v)) == 0 and v.value == 1024
+    assert lib.osi_set_tuning(b"wgrad_blocks", 2048) == 0
+    assert lib.osi_set_tuning(b"wgrad_nst", 3) == -1 and lib.osi_set_tuning(b"no_such_knob", 1) == -1
+    h = ctypes.c_void_p()
+    assert lib.osi_resnet50_create(ctypes.byref(h), 2, 64, 64, 5, 5, 0) == 0
+    try:
+        assert lib.osi_resnet50_set_option(h, b"overlap", 0) == 0 and lib.osi_resnet50_set_option(h, b"fwd_fork", 0) == 0
+        assert lib.osi_resnet50_set_option(h, b"side_priority_normal", 1) == 0
+        assert lib.osi_resnet50_set_option(h, b"bogus", 1) == -1
+        assert lib.osi_resnet50_bind_input_nhwc4(h, None) == -1 and lib.osi_resnet50_bind_input_nhwc4(h, 24) == -1   # NULL / unaligned
+    finally:
+        lib.osi_resnet50_destroy(h)
+    src = "".join(open(os.path.join(os.path.dirname(__file__), "..", "openset-imagenet_amd", "csrc", f)).read()
+                  for f in ("conv_igemm.hip", "bn.hip", "resnet50_exec.hip", "pool_layout.hip", "loss.hip", "optim.hip", "linear.hip"))
+    assert "getenv" not in src
+
+
+def test_host_side_of_the_input_pipeline(tmp_path):
+    """Resize(256) / CenterCrop(224) size rules and the canvas window (host logic of pipeline.CanvasDataset) against PIL."""
+    from PIL import Image
+    from openset_imagenet import pipeline as P
+    assert P.resize_size(500, 375) == (341, 256) and P.resize_size(375, 500) == (256, 341) and P.resize_size(256, 256) == (256, 256)
+    assert P.resize_size(1000, 333) == (int(256 * 1000 / 333), 256)                       # torchvision: int(), not round()
+    assert P.center_crop_corner(341, 256) == (int(round(117 / 2.0)), 16) == (58, 16)      # Python rounding (banker's) like torchvision
+    assert P.center_crop_corner(343, 256)[0] == int(round(119 / 2.0)) == 60
+    rng = np.random.default_rng(1)
+    arr = rng.integers(0, 256, size=(256, 341, 3), dtype=np.uint8)
+    for x0, y0 in ((0, 0), (117, 32), (60, 7), (100, 31)):
+        win, cx, cy = P.canvas_window(arr, x0, y0)
+        assert win.shape == (256, 256, 3) and 0 <= cx <= 32 and 0 <= cy <= 32
+        assert np.array_equal(win[cy:cy + 224, cx:cx + 224], arr[y0:y0 + 224, x0:x0 + 224])
+    # the dataset object end to end on two JPEG files (CPU part only: decode, resize, window, labels)
+    rows = []
+    for i, (w, h) in enumerate(((400, 300), (280, 390))):
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(tmp_path / f"{i}.jpg", quality=95)
+        rows.append(f"{i}.jpg,{i - 1}")
+    (tmp_path / "p.csv").write_text("\n".join(rows) + "\n")
+    ds = oi.ImagenetDataset(tmp_path / "p.csv", tmp_path, train=False, loss_type="entropic")
+    assert len(ds) == 2 and ds.table.label_count == 2 and ds.table.has_negatives()
+    canvas, crop, flip, label = ds[0]
+    assert canvas.shape == (256, 256, 3) and canvas.dtype == torch.uint8 and crop.dtype == torch.int32 and int(flip) == 0 and int(label) == -1
+    img = Image.open(tmp_path / "0.jpg").convert("RGB").resize((341, 256), Image.BILINEAR)
+    x0, y0 = P.center_crop_corner(341, 256)
+    ref = np.asarray(img.crop((x0, y0, x0 + 224, y0 + 224)))
+    cx, cy = (int(v) for v in crop)
+    assert np.array_equal(canvas.numpy()[cy:cy + 224, cx:cx + 224], ref)
+    x, y = oi.ImagenetDataset(tmp_path / "p.csv", tmp_path, train=False, loss_type="entropic", uint8=False)[0]   # the reference's own sample
+    assert x.shape == (3, 224, 224) and torch.equal(x, torch.from_numpy(ref.copy()).permute(2, 0, 1).float().div(255))
+    garbage = oi.ImagenetDataset(tmp_path / "p.csv", tmp_path, train=True, loss_type="garbage")
+    assert int(garbage[0][3]) == 1 and garbage.table.label_count == 2     # -1 relabelled to the last index (dataset.py:60-68)
+
+
+def test_dist_environment_and_launcher(monkeypatch, tmp_path):
+    from openset_imagenet.train import dist_env
+    from openset_imagenet.script import train as cli
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert dist_env() == (0, 1, None)
+    monkeypatch.setenv("RANK", "3"); monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("LOCAL_RANK", "3")
+    assert dist_env() == (3, 8, 3)
+    # the reference's `dist:` block is back in the configuration, default off
+    cfg = util.load_yaml(os.path.join(os.path.dirname(__file__), "..", "config", "train.yaml"))
+    assert cfg.dist.distributed is False and cfg.dist.gpus == 2 and str(cfg.dist.port) == "8889"
+    # distributed: on + no RANK in the environment -> the CLI becomes the launcher (one child per GPU, before any GPU call)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    cfg.dist.distributed = True
+    y = tmp_path / "d.yaml"
+    y.write_text(cfg.dump())
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env):
+            started.append((cmd, {k: env[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+
+        def wait(self):
+            return 0
+    monkeypatch.setattr(cli.subprocess, "Popen", lambda cmd, env: FakeProc(cmd, env))
+    assert cli.main([str(y), "2", "-g", "--nice", "0"]) == 0
+    assert [e["RANK"] for _, e in started] == ["0", "1"] and all(e["WORLD_SIZE"] == "2" and e["MASTER_ADDR"] == "127.0.0.1" and
+                                                               e["MASTER_PORT"] == "8889" for _, e in started)
+    assert started[0][0][1:3] == ["-m", "openset_imagenet.script.train"] and started[0][0][3:] == [str(y), "2", "-g", "--nice", "0"]

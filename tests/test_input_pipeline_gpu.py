@@ -104,3 +104,96 @@ def test_worker_on_jpeg_files(cuda, tmp_path, u8):
             ccr, fpr = calculate_oscr(a["gt"], a["scores"])
             occr, ofpr = oracle_oscr(a["gt"], a["scores"])
             assert np.array_equal(ccr, occr, equal_nan=True) and np.array_equal(fpr, ofpr, equal_nan=True)
+
+
+def test_device_crop_flip_equals_pil(cuda):
+    """The device side of Compose([Resize(256), RandomCrop(224) | CenterCrop(224), RandomHorizontalFlip, ToTensor]) (reference
+    train.py:259-268) after decode + resize: the canvas kernel against PIL's own crop() / transpose(FLIP_LEFT_RIGHT) followed by
+    the ToTensor division on the host — bit for bit, through the ctypes ABI and through torch.ops.osi.stage_canvas."""
+    from PIL import Image
+    from openset_imagenet import pipeline as P, _native as N
+    rng = np.random.default_rng(7)
+    canvases, crops, flips, refs = [], [], [], []
+    for i, (w, h) in enumerate(((341, 256), (256, 300), (256, 256), (420, 256), (256, 511))):
+        img = Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
+        x0, y0 = int(rng.integers(0, w - 224 + 1)), int(rng.integers(0, h - 224 + 1))
+        if i == 0:
+            x0, y0 = w - 224, h - 224                                    # the far corner
+        flip = bool(i % 2)
+        ref = img.crop((x0, y0, x0 + 224, y0 + 224))                     # RandomCrop
+        if flip:
+            ref = ref.transpose(Image.FLIP_LEFT_RIGHT)                   # RandomHorizontalFlip acts on the cropped image
+        refs.append(torch.from_numpy(np.asarray(ref).copy()).float().div(255))      # ToTensor (kept HWC for the comparison)
+        win, cx, cy = P.canvas_window(np.asarray(img), x0, y0)
+        canvases.append(torch.from_numpy(np.ascontiguousarray(win))); crops.append([cx, cy]); flips.append(int(flip))
+    canvas = torch.stack(canvases).to(cuda)
+    crop = torch.tensor(crops, dtype=torch.int32, device=cuda)
+    flip = torch.tensor(flips, dtype=torch.uint8, device=cuda)
+    ref = torch.stack(refs)
+    out = P.stage_canvas_batch(canvas, crop, flip)
+    assert out.shape == (5, 224, 224, 4) and torch.equal(out[..., :3].cpu(), ref) and float(out[..., 3].abs().max()) == 0
+    out2 = N.ops().stage_canvas(canvas, crop, flip, 224, 224)
+    assert torch.equal(out2, out)
+    # no crop table / no flips = top-left corner, unflipped; out-of-range corners are clamped on the device, never read outside
+    plain = N.ops().stage_canvas(canvas, None, None, 224, 224)
+    assert torch.equal(plain[..., :3].cpu(), canvas[:, :224, :224].cpu().float().div(255))
+    wild = torch.tensor([[-5, 999]] * 5, dtype=torch.int32, device=cuda)
+    clamped = N.ops().stage_canvas(canvas, wild, None, 224, 224)
+    assert torch.equal(clamped[..., :3].cpu(), canvas[:, 32:, :224].cpu().float().div(255)) and wild.cpu().tolist() == [[0, 32]] * 5
+
+
+def test_prefetcher_equals_synchronous_loop(cuda):
+    """DevicePrefetcher (copy stream, one batch ahead, event-ordered ring of staged batches): the batches it yields and a whole
+    train() epoch driven by it equal the synchronous path bit for bit — a race between the copy and the compute stream (a ring
+    slot rewritten while the stem weight gradient still reads it) would show up as different parameters."""
+    from openset_imagenet import ResNet50, EntropicOpensetLoss, AverageMeter, optim, tools, pipeline as P
+    from openset_imagenet.train import train
+    from openset_imagenet.util import NameSpace
+    tools.set_device_gpu(0)
+    g = torch.Generator().manual_seed(3)
+    n, C = 22, 5
+    canv = torch.randint(0, 256, (n, 256, 256, 3), dtype=torch.uint8, generator=g)
+    crop = torch.randint(0, 33, (n, 2), generator=g).to(torch.int32)
+    flip = (torch.rand(n, generator=g) < 0.5).to(torch.uint8)
+    lab = torch.randint(-1, C, (n,), generator=g)
+    ds = torch.utils.data.TensorDataset(canv, crop, flip, lab)
+    mk = lambda: torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=0, pin_memory=True)   # ragged last batch of 2
+    sync = [(P.stage_canvas_batch(c.to(cuda), xy.to(cuda), f.to(cuda)), y.to(cuda)) for c, xy, f, y in mk()]
+    pre = [(x.clone(), y.clone()) for x, y in P.DevicePrefetcher(mk())]
+    assert len(pre) == len(sync) == 6 and len(P.DevicePrefetcher(mk())) == 6
+    for (a, ya), (b, yb) in zip(pre, sync):
+        assert a.shape == b.shape and torch.equal(a, b) and torch.equal(ya, yb)
+
+    def epoch(loader):
+        torch.manual_seed(11)
+        model = tools.device(ResNet50(C, C, False))
+        opt = optim.Adam(model.parameters(), lr=1e-3)
+        tr = {"j": AverageMeter()}
+        train(model, loader, opt, EntropicOpensetLoss(C, 1.0), tr, NameSpace({"parallel": True}))
+        torch.cuda.synchronize()
+        return model.flat_parameters().clone(), model._flat_buffers.clone(), tr["j"].avg
+    a = epoch(P.DevicePrefetcher(mk()))
+    b = epoch([(x, y) for x, y in sync])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and np.isfinite(a[2])
+
+
+def test_metrics_module_matches_reference_vectors(cuda, golden_dir):
+    """metrics.confidence(scores, target, offset, unknown_class, last_valid_class) — the reference's own signature
+    (metrics.py:8-42) — against the vectors its implementation produced; predict_objectosphere against its definition."""
+    import os
+    from openset_imagenet import metrics
+    G = np.load(os.path.join(golden_dir, "losses_reference.npz"))
+    for name in G["conf.names"]:
+        p = f"conf.{name}."
+        off, unk, last = G[p + "args"]
+        r = metrics.confidence(torch.from_numpy(G[p + "scores"]).to(cuda), torch.from_numpy(G[p + "target"]).to(cuda), float(off),
+                               int(unk), None if last == -999 else int(last))
+        ref = G[p + "result"]
+        assert (r[1], r[3]) == (ref[1], ref[3]) and abs(r[0] - ref[0]) < 1e-6 and abs(r[2] - ref[2]) < 1e-6, p
+    g = torch.Generator().manual_seed(1)
+    z, f = torch.randn(9, 6, generator=g), torch.randn(9, 6, generator=g)
+    out = metrics.predict_objectosphere(z.to(cuda), f.to(cuda), 0.8).cpu()
+    s = torch.softmax(z, 1)
+    ps, pc = s.max(1)
+    pc = pc.clone(); pc[(f.norm(dim=1) * ps) < 0.8] = -1
+    assert torch.equal(out[:, 0].long(), pc) and torch.allclose(out[:, 1], ps, atol=1e-6)

@@ -1,0 +1,176 @@
+"""Whole-path GPU tests at the BASELINE.json workloads.
+
+  * Protocol-3 shape end to end against the oracle: C = 152 (151 known + background), background-class ("garbage") softmax
+    with class weights from `calculate_class_weights` (reference dataset.py:77-86, train.py:344-347), model forward + backward
+    against the fp32 / fp64 CPU oracle at a size the CPU affords (B = 8 at 96x96).
+  * Every BASELINE.json GPU configuration at its FULL size (B = 128 / 256 per GPU at 224x224) through size-independent
+    properties: finite, bit-reproducible, backward exactly linear in the upstream gradient, loss in range, BatchNorm counters,
+    one optimizer step moves every parameter tensor.
+  * The HIP model against the independent witness of the ResNet-50 body (transformers' ResNet v1.5, fp64 vectors committed
+    under tests/golden/resnet_witness.npz by tests/golden/make_golden_witness.py): logits within the 1e-4 north-star bar.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def _p3_labels(C, n, gen, p_bg=0.39):
+    """Synthetic Protocol-3 label column: known classes 0..C-2 and -1 (negatives) at the share SURVEY.md §8(d) uses."""
+    y = torch.randint(0, C - 1, (n,), generator=gen)
+    y[torch.rand(n, generator=gen) < p_bg] = -1
+    return y
+
+
+def test_protocol3_garbage_whole_path_vs_oracle(cuda):
+    from openset_imagenet import ResNet50, GarbageLoss
+    from openset_imagenet.dataset import LabelTable
+    from oracle import resnet50_oracle as R, losses_oracle as L
+    C, B, HW = 152, 8, 96
+    gen = torch.Generator().manual_seed(33)
+    sd = R.init_state(C, C, False, generator=gen)
+    model = ResNet50(C, C, False)
+    model.load_state_dict(sd)
+    model = model.to(cuda)
+    # class weights from a dataset-level label column, exactly as worker() does it (train.py:287-293,344-347)
+    csv_labels = torch.cat([torch.arange(C - 1).repeat(3), _p3_labels(C, 4000, gen)])
+    table = LabelTable(csv_labels.numpy())
+    table.replace_negative_label()
+    cw = table.calculate_class_weights()
+    assert cw.numel() == C and table.label_count == C
+    assert np.allclose(cw.numpy(), L.class_weights(csv_labels).numpy(), rtol=1e-6)
+    x = torch.rand(B, 3, HW, HW, generator=gen)
+    y = _p3_labels(C, B, gen)
+    y[y < 0] = C - 1                                  # replace_negative_label on the batch labels
+    y[0] = C - 1                                      # at least one background sample
+    model.train()
+    logits, feats = model(x.to(cuda))
+    j = GarbageLoss(cw)(logits, y.to(cuda))
+    j.backward()
+    torch.cuda.synchronize()
+    ref_fn = lambda lg, t, f: L.garbage_loss(lg, t, cw.to(lg.dtype))
+    r32 = R.forward_backward({k: v.clone() for k, v in sd.items()}, x, y, ref_fn)
+    r64 = R.forward_backward({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}, x.double(), y, ref_fn)
+    lg = logits.detach().cpu()
+    e32, e64 = float((lg - r32[0]).abs().max()), float((lg.double() - r64[0]).abs().max())
+    print(f"P3 C=152: max|logit - oracle32|={e32:.2e} |logit - oracle64|={e64:.2e}")
+    assert lg.shape == (B, C) and e32 <= LOGIT_TOL and e64 <= LOGIT_TOL
+    assert float((feats.detach().cpu().double() - r64[1]).abs().max()) <= 2 * LOGIT_TOL
+    assert abs(float(j) - float(r64[2])) <= 1e-5 * max(1.0, abs(float(r64[2])))
+    named = dict(model.named_parameters())
+    mine, ref = [], []
+    for k in R.param_keys(sd):
+        g = named[k].grad.detach().cpu()
+        mine.append(_rel(g, r64[3][k])); ref.append(_rel(r32[3][k], r64[3][k]))
+        assert mine[-1] <= 5 * ref[-1] + 2e-4, f"grad {k}: rel err {mine[-1]:.2e} (torch-cpu-fp32: {ref[-1]:.2e})"
+    assert np.median(mine) <= 2 * np.median(ref) + 1e-5
+    # the head gradients carry the class weights directly: tight check
+    assert _rel(named["logits.weight"].grad.cpu(), r64[3]["logits.weight"]) <= 5 * _rel(r32[3]["logits.weight"], r64[3]["logits.weight"]) + 1e-5
+
+
+WORKLOADS = {
+    # BASELINE.json configs 2..5
+    "p1_entropic_b128": dict(C=116, B=128, loss="entropic", p_neg=0.37),
+    "p2_entropic_b128": dict(C=30, B=128, loss="entropic", p_neg=0.5),
+    "p2_objectosphere_b128": dict(C=30, B=128, loss="objectosphere", p_neg=0.5),
+    "p3_garbage_b256": dict(C=152, B=256, loss="garbage", p_neg=0.39),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WORKLOADS))
+def test_full_size_workload_step(cuda, name):
+    from openset_imagenet import ResNet50, EntropicOpensetLoss, GarbageLoss, ObjectosphereLoss, optim
+    from openset_imagenet.dataset import LabelTable
+    wl = WORKLOADS[name]
+    C, B = wl["C"], wl["B"]
+    torch.manual_seed(7)
+    gen = torch.Generator().manual_seed(11)
+    model = ResNet50(C, C, False).to(cuda)
+    opt = optim.Adam(model.parameters(), lr=1e-3)
+    x = torch.rand(B, 3, 224, 224, device=cuda)
+    if wl["loss"] == "garbage":
+        y = _p3_labels(C, B, gen, wl["p_neg"])
+        table = LabelTable(torch.cat([torch.arange(C - 1).repeat(2), _p3_labels(C, 5000, gen, wl["p_neg"])]).numpy())
+        table.replace_negative_label()
+        y[y < 0] = C - 1
+        loss = GarbageLoss(table.calculate_class_weights())
+        call = lambda lg, ft: loss(lg, y_d)
+    else:
+        y = torch.randint(0, C, (B,), generator=gen)
+        y[torch.rand(B, generator=gen) < wl["p_neg"]] = -1
+        if wl["loss"] == "objectosphere":
+            loss = ObjectosphereLoss(C, 1.0, xi=10.0, alpha=1e-4)
+            call = lambda lg, ft: loss(lg, y_d, ft)
+        else:
+            loss = EntropicOpensetLoss(C, 1.0)
+            call = lambda lg, ft: loss(lg, y_d)
+    y_d = y.to(cuda)
+    runs = []
+    for scale in (1.0, 1.0, 2.0):
+        model.train()
+        opt.zero_grad()
+        logits, feats = model(x)
+        j = call(logits, feats) * scale
+        j.backward()
+        runs.append((logits.detach().clone(), feats.detach().clone(), model.flat_gradients().clone(), float(j)))
+    torch.cuda.synchronize()
+    lg, ft, g, jv = runs[0]
+    assert lg.shape == (B, C) and ft.shape == (B, C)
+    assert torch.isfinite(lg).all() and torch.isfinite(ft).all() and torch.isfinite(g).all()
+    assert torch.equal(lg, runs[1][0]) and torch.equal(g, runs[1][2]), "same inputs must give the same bits"
+    assert torch.equal(runs[2][2], g * 2), "backward is linear in the upstream gradient"
+    assert 0 < jv < 3 * np.log(C), jv
+    # every one of the 162 parameter tensors received a gradient with some non-zero entry
+    named = dict(model.named_parameters())
+    assert len(named) == 162
+    for k, p in named.items():
+        assert p.grad is not None and float(p.grad.abs().max()) > 0, k
+    st = model.state_dict()
+    assert int(st["resnet_base.bn1.num_batches_tracked"]) == 3 and int(st["resnet_base.layer4.2.bn3.num_batches_tracked"]) == 3
+    assert torch.isfinite(model._flat_buffers).all() and float(st["resnet_base.layer3.0.bn2.running_var"].min()) > 0
+    before = model.flat_parameters().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    delta = (model.flat_parameters() - before).abs()
+    assert torch.isfinite(model.flat_parameters()).all()
+    # Adam's first step moves every parameter with a non-zero gradient by ~lr
+    assert float(delta.max()) <= 1.01e-3 and float((delta > 0).float().mean()) > 0.95
+
+
+def test_hip_model_vs_transformers_witness(cuda, golden_dir):
+    """The product path against the independent implementation of the body (no oracle in between): fp32 HIP logits / features
+    vs the fp64 transformers-ResNet vectors, train and eval mode, plus the running-statistics update."""
+    from openset_imagenet import ResNet50
+    from oracle import resnet50_oracle as R          # only for the seeded weight generator the witness script used
+    W = np.load(os.path.join(golden_dir, "resnet_witness.npz"))
+    for tag in W["names"]:
+        B, HW, C, seed = (int(v) for v in W[f"{tag}.meta"])
+        gen = torch.Generator().manual_seed(seed)
+        sd = R.randomize_bn(R.init_state(C, C, False, generator=gen), gen)
+        x = torch.rand(B, 3, HW, HW, generator=gen).to(cuda)
+        for mode in ("train", "eval"):
+            model = ResNet50(C, C, False)
+            model.load_state_dict(sd)
+            model = model.to(cuda)
+            model.train(mode == "train")
+            with torch.no_grad():
+                logits, feats = model(x)
+            p = f"{tag}.{mode}."
+            el = float((logits.cpu().double().numpy() - W[p + "logits"]).__abs__().max())
+            ef = float((feats.cpu().double().numpy() - W[p + "features"]).__abs__().max())
+            print(f"{p} max|logit - witness|={el:.2e} max|feature - witness|={ef:.2e}")
+            assert el <= LOGIT_TOL and ef <= 2 * LOGIT_TOL
+            if mode == "train":
+                st = model.state_dict()
+                for key in W.files:
+                    if key.startswith(p + "resnet_base.") and key.endswith(("running_mean", "running_var")):
+                        assert np.allclose(st[key[len(p):]].cpu().double().numpy(), W[key], rtol=1e-4, atol=1e-5), key

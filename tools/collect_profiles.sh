@@ -7,6 +7,8 @@ set -e
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/${1:-prof_final}
 mkdir -p "$OUT"
+echo "${OSI_COMMIT:-unknown}" > "$OUT/commit.txt"
+python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 # the same with the weight gradients kept on the main stream (no co-running kernels): per-kernel averages comparable with the
