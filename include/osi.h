@@ -59,6 +59,13 @@ int osi_conv_fwd(const osi_conv_desc* d, const float* x, const float* w, float* 
 size_t osi_conv_fwd_bnstats_workspace(const osi_conv_desc* d);
 int osi_conv_fwd_bnstats(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, float* pstats,
                          size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
+/* Forward convolution whose INPUT is the previous layer's BatchNorm + ReLU applied on the fly: the A operand is
+ * relu(x * in_scale[c] + in_shift[c]) computed in the loader (x = the producer's pre-BN output, in_scale / in_shift [Cin] from
+ * osi_bn_finalize_stats / osi_bn_eval_coeffs), zero padding applied AFTER the activation as conv2d pads the activation tensor.
+ * Replaces conv2d(relu(bn(x)), w) of the Bottleneck (conv2 / conv3) without the activation ever touching HBM. pstats may be NULL
+ * (then P / rows_per_block are ignored); tiles: OSI_TILE_AUTO, OSI_TILE_64x64_S1, OSI_TILE_64x128_S1. */
+int osi_conv_fwd_act(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
+                     int tile, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
 /* dx (+)= conv2d_input_grad(dy, w). accumulate != 0 adds into dx (skip-connection sum). Cout % 32 == 0, Cin % 64 == 0. */
 int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, int tile,
                    osi_stream_t stream);
@@ -77,6 +84,8 @@ typedef struct {
     const float* invstd1;
     float* partials;        /* NULL: no reductions */
     size_t partials_bytes;  /* >= osi_conv_dgrad_fused_workspace(d) */
+    const float* scale0;    /* alternative gate when relu_mask == NULL: the producer's activation relu(y0 * scale0 + shift0) was */
+    const float* shift0;    /* never stored (osi_conv_fwd_act consumed y0 directly), so the gate is recomputed: on where > 0 */
 } osi_dgrad_fusion;
 size_t osi_conv_dgrad_fused_workspace(const osi_conv_desc* d);
 int osi_conv_dgrad_fused(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,
@@ -86,6 +95,9 @@ int osi_conv_dgrad_fused(const osi_conv_desc* d, const float* dy, const float* w
 size_t osi_conv_wgrad_workspace(const osi_conv_desc* d);
 int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, float* dw, void* ws, size_t ws_bytes,
                    osi_stream_t stream);
+/* The same with x replaced by relu(x * in_scale[c] + in_shift[c]) in the loader (the conv's input activation was never stored). */
+int osi_conv_wgrad_act(const osi_conv_desc* d, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
+                       void* ws, size_t ws_bytes, osi_stream_t stream);
 int osi_stem_weight_pack(const float* w_krsc3, float* w_packed, int Cout, osi_stream_t stream);
 int osi_stem_grad_unpack(const float* g_packed, float* g_krsc3, int Cout, osi_stream_t stream);
 

@@ -232,7 +232,10 @@ __global__ __launch_bounds__(NT) void k_bn_apply(const f32x4* __restrict__ y, co
     const size_t step = (size_t)gridDim.x * NT;
     for (; i < n4; i += step) {
         int c4 = (int)(i % (size_t)c4n);
-        f32x4 v = y[i] * scale[c4] + shift[c4];
+        const f32x4 yv = y[i], sc = scale[c4], sh = shift[c4];
+        f32x4 v;   // one fma per element: the same expression the fused conv loaders and the dgrad gate evaluate
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(yv[e], sc[e], sh[e]);
         if (RES) v += res[i];
         if (BITS) {
             const u64 b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);

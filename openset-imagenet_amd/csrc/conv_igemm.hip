@@ -52,12 +52,18 @@ struct ConvP {
     const float* ey0;
     const float* ey1;
     const float *emean0, *einv0, *emean1, *einv1;  // batch mean / invstd of the consumer BatchNorm(s): xhat = (y - mean) * invstd
+    const float *escale0, *eshift0;                // ReLU gate recomputed from ey0 (no bitmask): on where ey0 * scale + shift > 0
     float* esum;
     int eP;
     // wgrad only
     int kchunk;       // pixels per split
     int wtbl;         // generic loader: rolling table of input byte offsets in LDS instead of per-row divisions
     int wgroup, splits;  // XCD-aware (cell, tap) block mapping on a 1-D grid; number of K splits
+    // fused input activation (fwd A operand / wgrad X operand): the operand is relu(x * in_scale[c] + in_shift[c]) — the BatchNorm +
+    // ReLU of the producer layer applied in the loader, so the activation tensor is never materialised. Zero padding / rows past
+    // the end stay exact zeros (the select runs AFTER the activation).
+    const float* in_scale;
+    const float* in_shift;
     size_t slab_stride;
 };
 
@@ -155,12 +161,23 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // ======================================================================================================
 // NST = LDS stages: 2 = double buffered (one barrier per K tile), 1 = single buffered (two barriers, half the LDS, twice the
 // resident workgroups per CU)
-template <int WM, int WN, bool STEM, int NST>
+// XF: the A operand is relu(x * in_scale[c] + in_shift[c]) (fused BatchNorm-apply + ReLU of the producer layer)
+template <int WM, int WN, bool STEM, int NST, bool XF = false>
 __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_conv_fwd(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32, BR = BN / 32;  // float4 loads per thread per stage
     constexpr int STAGE = (BM + BN) * LDR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(!(XF && STEM), "the stem reads the image, not an activation");
+    float* s_sc = smem + NST * STAGE;          // XF: per-input-channel scale | shift tables, behind the operand stages
+    float* s_sh = s_sc + p.Cin;
+    if (XF) {
+        for (int c = threadIdx.x * 4; c < p.Cin; c += 1024) {
+            *reinterpret_cast<f32x4*>(s_sc + c) = ld4(p.in_scale + c);
+            *reinterpret_cast<f32x4*>(s_sh + c) = ld4(p.in_shift + c);
+        }
+        // visible to every wave after the first __syncthreads() below (before any sstore of transformed data is read)
+    }
 
     int mt, nt;
     if (!tile_of_block(blockIdx.x, p.MT, p.NT, mt, nt)) return;
@@ -212,9 +229,11 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
 
     const int T = p.Ktot / BK;
     int r = 0, s = 0, c0 = 0;  // current tap / channel offset (non-stem)
+    int ld_c0 = 0, ld_tap = 0; // XF: channel offset / tap index of the tile sitting in ra (set by gload, used by sstore)
     f32x4 ra[AR], rb[BR];
 
     auto gload = [&](int t) {
+        if (XF) { ld_c0 = p.unit ? t * BK : c0; ld_tap = r * p.S + s; }
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             if (STEM) {
@@ -242,13 +261,28 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
     auto sstore = [&](int buf) {
         float* sA = smem + buf * STAGE;
         float* sB = sA + BM * LDR;
+        if (XF) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + ld_c0 + kq * 4), sh = *reinterpret_cast<const f32x4*>(s_sh + ld_c0 + kq * 4);
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+            for (int i = 0; i < AR; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(ra[i][e], sc[e], sh[e]), 0.f);
+                // 1x1 stride-1: only rows past M are invalid and their results are never stored; otherwise padding taps must read
+                // as the zero the reference pads the ACTIVATION with
+                const bool ok = p.unit ? true : (((a_taps[i] >> ld_tap) & 1) != 0);
+                *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+        }
 #pragma unroll
         for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(sB + (lr + 32 * i) * LDR + kq * 4) = rb[i];
     };
 
     gload(0); advance();
+    if (XF) __syncthreads();   // the scale / shift tables are complete
     sstore(0);
     __syncthreads();
     for (int t = 0; t < T; ++t) {
@@ -482,11 +516,12 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         __syncthreads();
         const int c4 = tid & 15, rg = tid >> 4;
         const int col = n0 + c4 * 4;
-        f32x4 sg = {0, 0, 0, 0}, s0 = sg, s1 = sg, mu0 = sg, is0 = sg, mu1 = sg, is1 = sg;
+        f32x4 sg = {0, 0, 0, 0}, s0 = sg, s1 = sg, mu0 = sg, is0 = sg, mu1 = sg, is1 = sg, gsc = sg, gsh = sg;
         if (FUSED && p.esum) {
             mu0 = ld4(p.emean0 + col); is0 = ld4(p.einv0 + col);
             if (p.ey1) { mu1 = ld4(p.emean1 + col); is1 = ld4(p.einv1 + col); }
         }
+        if (FUSED && p.escale0) { gsc = ld4(p.escale0 + col); gsh = ld4(p.eshift0 + col); }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int rl = rg + 16 * k;
@@ -511,9 +546,15 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
                     v[0] = (w01.x >> bit) & 1 ? v[0] : 0.f; v[1] = (w01.y >> bit) & 1 ? v[1] : 0.f;
                     v[2] = (w23.x >> bit) & 1 ? v[2] : 0.f; v[3] = (w23.y >> bit) & 1 ? v[3] : 0.f;
                 }
+                f32x4 y0v = {0, 0, 0, 0};
+                if (p.escale0 || p.esum) y0v = ld4(p.ey0 + off);
+                if (p.escale0) {   // the producer's activation was never stored: its ReLU gate is recomputed from the pre-BN tensor
+#pragma unroll               // with the very expression (one fma) the forward loader used
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(y0v[e], gsc[e], gsh[e]) > 0.f ? v[e] : 0.f;
+                }
                 if (p.esum) {    // BatchNorm-backward partial sums of the consumer(s): sum g, sum g*xhat0 [, sum g*xhat1]
                     sg += v;
-                    s0 += (v * (ld4(p.ey0 + off) - mu0)) * is0;
+                    s0 += (v * (y0v - mu0)) * is0;
                     if (p.ey1) s1 += (v * (ld4(p.ey1 + off) - mu1)) * is1;
                 }
             }
@@ -594,6 +635,12 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
                             v[e] = (w >> (i4 & 63)) & 1 ? v[e] : 0.f;
                         }
                     }
+                    if (p.escale0) {  // ReLU gate recomputed from the producer's pre-BN tensor (see the 64x64 form above)
+                        const float gsc = p.escale0[col], gsh = p.eshift0[col];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = (rok[e] && __builtin_fmaf(p.ey0[roff[e] + col], gsc, gsh) > 0.f) ? v[e] : 0.f;
+                    }
                     if (p.esum) {   // BatchNorm-backward partial sums of the consumer(s): sum g, sum g*xhat0 [, sum g*xhat1]
                         const float mu0 = p.emean0[col], is0 = p.einv0[col];
 #pragma unroll
@@ -645,8 +692,10 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
 // Weight gradient. GEMM rows = cout, cols = (tap, cin range), K = pixels. blockIdx.y = K split.
 // STEM: Cin = 4 (padded RGB), 56 padded taps -> 224 columns, a column tile spans 16 taps.
 // ======================================================================================================
-template <int WM, int WN, bool STEM, int NST>
+// XF: the X operand is relu(x * in_scale[c] + in_shift[c]) (the producer layer's BatchNorm + ReLU applied in the loader)
+template <int WM, int WN, bool STEM, int NST, bool XF = false>
 __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
+    static_assert(!(XF && STEM), "the stem reads the image, not an activation");
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int AV = BM / 4, ARP = 256 / AV, ARN = BK / ARP;
@@ -706,6 +755,16 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
     constexpr int TW = 32;
     uint32_t* tbl = reinterpret_cast<uint32_t*>(smem + NST * STAGE);
     const bool use_tbl = !STEM && p.wtbl;
+    float* s_sc = smem + NST * STAGE + TW * BK;   // XF: scale | shift of this workgroup's BN input channels (behind the offset table)
+    float* s_sh = s_sc + BN;
+    if (XF) {
+        if (tid < BN / 4) {
+            *reinterpret_cast<f32x4*>(s_sc + tid * 4) = ld4(p.in_scale + c0 + tid * 4);
+            *reinterpret_cast<f32x4*>(s_sh + tid * 4) = ld4(p.in_shift + c0 + tid * 4);
+        }
+        __syncthreads();
+    }
+    int ld_t = 0;   // XF: K tile sitting in rbv
     auto build_tbl = [&](int t0) {
         for (int i = tid; i < TW * BK; i += 256) {
             const int m = kbeg + t0 * BK + i;
@@ -725,6 +784,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
     };
     auto gload = [&](int t) {
         const int kb = kbeg + t * BK;
+        ld_t = t;
 #pragma unroll
         for (int i = 0; i < ARN; ++i) {   // dY rows: pixel part in the scalar offset, zero rows past the split's end via OOB
             const int m = kb + a_row + ARP * i;
@@ -763,8 +823,22 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
         float* sB = sA + BK * LDA;
 #pragma unroll
         for (int i = 0; i < ARN; ++i) *reinterpret_cast<f32x4*>(sA + (a_row + ARP * i) * LDA + a_col) = ra[i];
+        if (XF) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + b_col), sh = *reinterpret_cast<const f32x4*>(s_sh + b_col);
 #pragma unroll
-        for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (b_row + BRP * i) * LDB + b_col) = rbv[i];
+            for (int i = 0; i < BRN; ++i) {
+                const int row = b_row + BRP * i;
+                // a zero operand row (pixel past the split's end, or a padding tap) must stay zero: select after the activation
+                const bool ok = p.unit ? (kbeg + ld_t * BK + row < kend) : (tbl[(ld_t % TW) * BK + row] != OOB);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(rbv[i][e], sc[e], sh[e]), 0.f);
+                *reinterpret_cast<f32x4*>(sB + row * LDB + b_col) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (b_row + BRP * i) * LDB + b_col) = rbv[i];
+        }
     };
 
     if (T > 0) {
@@ -876,14 +950,15 @@ static ConvP make_p(const osi_conv_desc* d) {
     return p;
 }
 
-template <int WM, int WN, bool STEM, int NST = 2>
+template <int WM, int WN, bool STEM, int NST = 2, bool XF = false>
 static int launch_fwd(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     p.MT = osi_cdiv(p.M, BM); p.NT = p.Cout / BN;
     size_t smem = NST * (size_t)(BM + BN) * LDR * sizeof(float);
-    if (int e = set_smem(k_conv_fwd<WM, WN, STEM, NST>, smem)) return e;
+    if (XF) smem += (size_t)2 * p.Cin * sizeof(float);
+    if (int e = set_smem(k_conv_fwd<WM, WN, STEM, NST, XF>, smem)) return e;
     int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
-    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM, NST>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM, NST, XF>), dim3(grid), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
@@ -911,13 +986,13 @@ static int launch_dgrad_impl(ConvP p, hipStream_t st) {
 template <int WM, int WN, int NST = 2>
 static int launch_dgrad(ConvP p, hipStream_t st) {
     // the fused epilogue (mask / BatchNorm reductions) is its own instantiation so that plain launches keep the small one
-    if (p.ebits || p.esum) {
+    if (p.ebits || p.esum || p.escale0) {
         if (NST != 1 || WM != 1) return OSI_ERR_ARG;   // fusion is built for the single-buffered 64-row tiles the executor uses
         return launch_dgrad_impl<1, WN, 1, true>(p, st);
     }
     return launch_dgrad_impl<WM, WN, NST, false>(p, st);
 }
-template <int WM, int WN, bool STEM, int NST = 2>
+template <int WM, int WN, bool STEM, int NST = 2, bool XF = false>
 static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     p.MT = p.Cout / BM;
@@ -925,17 +1000,18 @@ static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
     size_t smem = 2 * (size_t)BK * (BM + 4 + BN + 4) * sizeof(float);
     smem = smem / 2 * NST;
     p.wtbl = (!STEM && !p.unit) ? 1 : 0;
-    if (p.wtbl) smem += 32 * BK * sizeof(uint32_t);   // TW * BK offsets
-    if (int e = set_smem(k_conv_wgrad<WM, WN, STEM, NST>, smem)) return e;
+    if (p.wtbl || XF) smem += 32 * BK * sizeof(uint32_t);   // TW * BK offsets
+    if (XF) smem += 2 * BN * sizeof(float);                 // scale | shift of the column tile's channels
+    if (int e = set_smem(k_conv_wgrad<WM, WN, STEM, NST, XF>, smem)) return e;
     p.splits = splits;
     p.wgroup = (g_osi_tuning.wgrad_group != 0) ? 1 : 0;
     if (p.wgroup) {
         const int taps = STEM ? 1 : p.R * p.S;
         const long cells = (long)p.MT * (p.NT / taps) * splits;
         const long grid = (cells + 7) / 8 * 8 * taps;
-        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST>), dim3((unsigned)grid), dim3(256), smem, st, p);
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST, XF>), dim3((unsigned)grid), dim3(256), smem, st, p);
     } else {
-        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST>), dim3(p.MT * p.NT, splits), dim3(256), smem, st, p);
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST, XF>), dim3(p.MT * p.NT, splits), dim3(256), smem, st, p);
     }
     OSI_LAUNCH_CHECK();
     return OSI_OK;
@@ -980,10 +1056,18 @@ static int fwd_tile_rows(int tile) {
     return (tile == OSI_TILE_128x128 || tile == OSI_TILE_128x64 || tile == OSI_TILE_128x128_S1 || tile == OSI_TILE_128x64_S1) ? 128 : 64;
 }
 static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, float* pstats,
-                         size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
+                         size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream, const float* in_scale = nullptr,
+                         const float* in_shift = nullptr);
 
 int osi_conv_fwd(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, osi_stream_t stream) {
     return conv_fwd_impl(d, x, w, y, tile, nullptr, 0, nullptr, nullptr, stream);
+}
+
+int osi_conv_fwd_act(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
+                     int tile, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream) {
+    OSI_REQUIRE(in_scale && in_shift);
+    OSI_REQUIRE(!pstats || (P && rows_per_block));
+    return conv_fwd_impl(d, x, w, y, tile, pstats, pstats_bytes, P, rows_per_block, stream, in_scale, in_shift);
 }
 
 size_t osi_conv_fwd_bnstats_workspace(const osi_conv_desc* d) {
@@ -999,11 +1083,14 @@ int osi_conv_fwd_bnstats(const osi_conv_desc* d, const float* x, const float* w,
 }
 
 static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, float* pstats,
-                         size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream) {
+                         size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream, const float* in_scale,
+                         const float* in_shift) {
     OSI_REQUIRE(desc_ok(d) && x && w && y);
     hipStream_t st = (hipStream_t)stream;
     ConvP p = make_p(d);
     p.x = x; p.w = w; p.y = y; p.accumulate = 0;
+    p.in_scale = in_scale; p.in_shift = in_shift;
+    OSI_REQUIRE(!in_scale || (!is_stem(d) && d->Cin <= 4096 && d->R * d->S <= 32));
     p.unit = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) ? 1 : 0;
     p.x_bytes = (int)((size_t)d->B * d->H * d->W * d->Cin * 4);
     p.w_bytes = (int)((size_t)d->Cout * p.Ktot * 4);
@@ -1032,6 +1119,11 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
         tile = (tiles64 < 1024 && d->Cout % 128 == 0) ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
     }
     if (int e = with_stats(fwd_tile_rows(tile))) return e;
+    if (in_scale) {   // fused input activation: built for the single-buffered 64-row tiles the executor uses
+        if (tile == OSI_TILE_64x64_S1) return launch_fwd<1, 1, false, 1, true>(p, st);
+        if (tile == OSI_TILE_64x128_S1) { OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<1, 2, false, 1, true>(p, st); }
+        return OSI_ERR_ARG;
+    }
     switch (tile) {
         case OSI_TILE_128x128: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<2, 2, false>(p, st);
         case OSI_TILE_128x64: return launch_fwd<2, 1, false>(p, st);
@@ -1083,8 +1175,11 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     // on every ResNet-50 shape (the dgrad class went 12.1 -> 11.0 ms per step against the 64x128 rule used before).
     if (tile == OSI_TILE_AUTO) tile = OSI_TILE_64x64_S1;
     if (f) {
-        OSI_REQUIRE(f->relu_mask || !f->partials);
+        OSI_REQUIRE(f->relu_mask || f->scale0 || !f->partials);
+        OSI_REQUIRE(!f->scale0 || (!f->relu_mask && f->shift0 && f->y0));   // one gate source: the bitmask, or y0 * scale0 + shift0 > 0
         p.ebits = (const unsigned long long*)f->relu_mask;
+        p.escale0 = f->scale0; p.eshift0 = f->shift0;
+        if (f->scale0) p.ey0 = f->y0;
         if (f->partials) {
             OSI_REQUIRE(f->y0 && f->mean0 && f->invstd0 && (!f->y1 || (f->mean1 && f->invstd1)));
             p.emean0 = f->mean0; p.einv0 = f->invstd0; p.emean1 = f->mean1; p.einv1 = f->invstd1;
@@ -1116,9 +1211,24 @@ size_t osi_conv_wgrad_workspace(const osi_conv_desc* d) {
     return w.splits > 1 ? (size_t)w.splits * n * sizeof(float) : 0;
 }
 
+static int conv_wgrad_impl(const osi_conv_desc* d, const float* dy, const float* x, float* dw, void* ws, size_t ws_bytes,
+                           osi_stream_t stream, const float* in_scale, const float* in_shift);
+
 int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, float* dw, void* ws, size_t ws_bytes,
                    osi_stream_t stream) {
+    return conv_wgrad_impl(d, dy, x, dw, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+int osi_conv_wgrad_act(const osi_conv_desc* d, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
+                       void* ws, size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(in_scale && in_shift);
+    return conv_wgrad_impl(d, dy, x, dw, ws, ws_bytes, stream, in_scale, in_shift);
+}
+
+static int conv_wgrad_impl(const osi_conv_desc* d, const float* dy, const float* x, float* dw, void* ws, size_t ws_bytes,
+                           osi_stream_t stream, const float* in_scale, const float* in_shift) {
     OSI_REQUIRE(desc_ok(d) && dy && x && dw);
+    OSI_REQUIRE(!in_scale || !is_stem(d));
     const bool stem = is_stem(d);
     OSI_REQUIRE(d->Cout % 64 == 0 && (stem || d->Cin % 64 == 0));
     hipStream_t st = (hipStream_t)stream;
@@ -1132,11 +1242,18 @@ int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, floa
     p.x_bytes = (int)((size_t)d->B * d->H * d->W * d->Cin * 4);
     p.w_bytes = (int)((size_t)d->B * d->Ho * d->Wo * d->Cout * 4);
     p.kchunk = w.kchunk; p.slab_stride = n;
+    p.in_scale = in_scale; p.in_shift = in_shift;
     int e;
     // Single-buffered LDS by default (as in fwd/dgrad: twice the resident workgroups beat staging depth): 11.4 -> 10.3 ms per step
     // for the wgrad class and -0.45 ms on the overlapped step, measured with the side-stream schedule of the executor.
     const int nst = g_osi_tuning.wgrad_nst;
-    if (stem) e = launch_wgrad<1, 1, true>(p, w.splits, st);
+    if (in_scale) {   // fused input activation: single-buffered forms only (the ones the executor uses)
+        if (w.wm == 2 && w.wn == 2) e = launch_wgrad<2, 2, false, 1, true>(p, w.splits, st);
+        else if (w.wm == 2) e = launch_wgrad<2, 1, false, 1, true>(p, w.splits, st);
+        else if (w.wn == 2) e = launch_wgrad<1, 2, false, 1, true>(p, w.splits, st);
+        else e = launch_wgrad<1, 1, false, 1, true>(p, w.splits, st);
+    }
+    else if (stem) e = launch_wgrad<1, 1, true>(p, w.splits, st);
     else if (w.wm == 2 && w.wn == 2) e = nst == 1 ? launch_wgrad<2, 2, false, 1>(p, w.splits, st) : launch_wgrad<2, 2, false>(p, w.splits, st);
     else if (w.wm == 2) e = nst == 1 ? launch_wgrad<2, 1, false, 1>(p, w.splits, st) : launch_wgrad<2, 1, false>(p, w.splits, st);
     else if (w.wn == 2) e = nst == 1 ? launch_wgrad<1, 2, false, 1>(p, w.splits, st) : launch_wgrad<1, 2, false>(p, w.splits, st);

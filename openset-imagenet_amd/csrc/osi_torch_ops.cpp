@@ -14,8 +14,9 @@
 // dispatcher / profiler see the ops by name; stream and lifetime safety no longer depend on the caller passing data_ptr()s.
 #include <torch/library.h>
 #include <ATen/ATen.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+// PyTorch-ROCm keeps the device type spelled "cuda"; these are its own HIP stream / guard classes for that spelling
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <optional>
 #include <string>
@@ -40,7 +41,7 @@ void need(const Tensor& t, at::ScalarType dt, const char* name) {
 }
 
 osi_stream_t stream_of(const Tensor& t) {
-    return (osi_stream_t)c10::hip::getCurrentHIPStream(t.device().index()).stream();
+    return (osi_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
 }
 
 osi_resnet50_t handle(int64_t h) {
@@ -57,7 +58,7 @@ std::tuple<Tensor, Tensor> resnet50_forward(int64_t net, const Tensor& params, T
     need(params, at::kFloat, "params"); need(buffers, at::kFloat, "buffers"); need(nbt, at::kLong, "num_batches_tracked");
     need(workspace, at::kByte, "workspace");
     TORCH_CHECK(image.dim() == 4, "osi::resnet50_forward: image must be 4-D");
-    c10::hip::HIPGuard guard(params.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(params.device());
     osi_resnet50_t h = handle(net);
     TORCH_CHECK((size_t)workspace.numel() >= osi_resnet50_workspace_bytes(h), "osi::resnet50_forward: workspace too small");
     TORCH_CHECK((size_t)params.numel() == osi_resnet50_param_floats(h), "osi::resnet50_forward: parameter arena size mismatch");
@@ -92,7 +93,7 @@ void resnet50_backward(int64_t net, const Tensor& params, Tensor grads, Tensor w
     need(dlogits, at::kFloat, "dlogits");
     if (dfeatures.has_value() && dfeatures->defined()) need(*dfeatures, at::kFloat, "dfeatures");
     TORCH_CHECK(grads.numel() == params.numel(), "osi::resnet50_backward: gradient arena size mismatch");
-    c10::hip::HIPGuard guard(params.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(params.device());
     ok(osi_resnet50_backward(handle(net), params.data_ptr<float>(), grads.data_ptr<float>(), workspace.data_ptr(),
                              dlogits.data_ptr<float>(), fptr(dfeatures), (int)stage_lo, (int)stage_hi, stream_of(params)),
        "osi_resnet50_backward");
@@ -105,7 +106,7 @@ std::tuple<Tensor, Tensor, Tensor> loss_fwd_bwd(int64_t mode, const Tensor& logi
     need(logits, at::kFloat, "logits"); need(target, at::kLong, "target");
     TORCH_CHECK(logits.dim() == 2 && target.dim() == 1 && target.size(0) == logits.size(0), "expected logits [B, C] and target [B]");
     const int B = (int)logits.size(0), C = (int)logits.size(1);
-    c10::hip::HIPGuard guard(logits.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(logits.device());
     Tensor loss = at::empty({}, logits.options());
     Tensor dlogits = need_grad ? at::empty_like(logits) : at::empty({0}, logits.options());
     Tensor dfeat = at::empty({0}, logits.options());
@@ -127,7 +128,7 @@ void adam_step(Tensor params, const Tensor& grads, Tensor exp_avg, Tensor exp_av
                int64_t step, double grad_scale) {
     need(params, at::kFloat, "params"); need(grads, at::kFloat, "grads"); need(exp_avg, at::kFloat, "exp_avg"); need(exp_avg_sq, at::kFloat, "exp_avg_sq");
     TORCH_CHECK(grads.numel() == params.numel() && exp_avg.numel() == params.numel() && exp_avg_sq.numel() == params.numel());
-    c10::hip::HIPGuard guard(params.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(params.device());
     ok(osi_adam_step(params.data_ptr<float>(), grads.data_ptr<float>(), exp_avg.data_ptr<float>(), exp_avg_sq.data_ptr<float>(),
                      (size_t)params.numel(), lr, beta1, beta2, eps, (long long)step, (float)grad_scale, stream_of(params)), "osi_adam_step");
 }
@@ -135,7 +136,7 @@ void adam_step(Tensor params, const Tensor& grads, Tensor exp_avg, Tensor exp_av
 void sgd_step(Tensor params, const Tensor& grads, Tensor momentum_buffer, double lr, double momentum, bool first, double grad_scale) {
     need(params, at::kFloat, "params"); need(grads, at::kFloat, "grads"); need(momentum_buffer, at::kFloat, "momentum_buffer");
     TORCH_CHECK(grads.numel() == params.numel() && momentum_buffer.numel() == params.numel());
-    c10::hip::HIPGuard guard(params.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(params.device());
     ok(osi_sgd_step(params.data_ptr<float>(), grads.data_ptr<float>(), momentum_buffer.data_ptr<float>(), (size_t)params.numel(),
                     (float)lr, (float)momentum, first ? 1 : 0, (float)grad_scale, stream_of(params)), "osi_sgd_step");
 }
@@ -147,7 +148,7 @@ Tensor stage_canvas(const Tensor& canvas, const std::optional<Tensor>& crop_xy, 
     int* cp = nullptr; const unsigned char* fl = nullptr;
     if (crop_xy.has_value() && crop_xy->defined()) { need(*crop_xy, at::kInt, "crop_xy"); TORCH_CHECK(crop_xy->numel() == 2 * B); cp = crop_xy->data_ptr<int>(); }
     if (flip.has_value() && flip->defined()) { need(*flip, at::kByte, "flip"); TORCH_CHECK(flip->numel() == B); fl = flip->data_ptr<unsigned char>(); }
-    c10::hip::HIPGuard guard(canvas.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(canvas.device());
     Tensor out = at::empty({B, H, W, 4}, canvas.options().dtype(at::kFloat));
     ok(osi_u8_crop_flip_to_nhwc4(canvas.data_ptr<unsigned char>(), cp, fl, out.data_ptr<float>(), B, (int)canvas.size(1), (int)canvas.size(2),
                                  (int)H, (int)W, stream_of(canvas)), "osi_u8_crop_flip_to_nhwc4");
@@ -156,7 +157,7 @@ Tensor stage_canvas(const Tensor& canvas, const std::optional<Tensor>& crop_xy, 
 
 Tensor softmax(const Tensor& logits) {
     need(logits, at::kFloat, "logits"); TORCH_CHECK(logits.dim() == 2);
-    c10::hip::HIPGuard guard(logits.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(logits.device());
     Tensor out = at::empty_like(logits);
     ok(osi_softmax(logits.data_ptr<float>(), out.data_ptr<float>(), (int)logits.size(0), (int)logits.size(1), stream_of(logits)), "osi_softmax");
     return out;
@@ -166,7 +167,7 @@ void confidence_accumulate(const Tensor& logits, const Tensor& target, double of
                            Tensor acc4) {
     need(logits, at::kFloat, "logits"); need(target, at::kLong, "target"); need(acc4, at::kDouble, "acc4");
     TORCH_CHECK(logits.dim() == 2 && target.numel() == logits.size(0) && acc4.numel() == 4);
-    c10::hip::HIPGuard guard(logits.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(logits.device());
     ok(osi_confidence_accumulate(logits.data_ptr<float>(), (const long long*)target.data_ptr<int64_t>(), (int)logits.size(0),
                                  (int)logits.size(1), (float)offset, (long long)unknown_class, (int)last_valid_class,
                                  acc4.data_ptr<double>(), stream_of(logits)), "osi_confidence_accumulate");

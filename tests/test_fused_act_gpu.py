@@ -1,0 +1,131 @@
+"""Convolutions that apply the producer layer's BatchNorm + ReLU in their operand loader (osi_conv_fwd_act, osi_conv_wgrad_act) and
+the input-gradient epilogue that recomputes the ReLU gate from the pre-BN tensor instead of a stored bitmask: the activation
+relu(bn(y)) between conv1 -> conv2 -> conv3 of a Bottleneck (torchvision Bottleneck.forward under reference model.py:37) is never
+written to HBM. Oracle: torch conv2d / conv2d_weight on the materialised activation in fp64; the gate path must equal the
+bitmask path bit for bit."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(64, 64, 1, 1, 14, 3), (64, 128, 3, 1, 9, 3), (128, 64, 3, 2, 9, 2), (256, 128, 1, 1, 7, 5), (64, 64, 3, 1, 20, 2),
+          (128, 256, 1, 2, 8, 3)]
+
+
+def _case(cuda, Cin, Cout, k, stride, H, B):
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + k + H)
+    x = (torch.randn(B, H, H, Cin, generator=g) * 1.5).to(cuda)
+    sc = (torch.rand(Cin, generator=g) + 0.5).to(cuda)
+    sh = (torch.randn(Cin, generator=g) * 0.7).to(cuda)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).to(cuda)
+    act64 = torch.relu(x.double() * sc.double() + sh.double())          # [B,H,W,Cin]
+    return x, sc, sh, w, act64
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,H,B", SHAPES)
+@pytest.mark.parametrize("tile", [0, 5, 6])
+def test_conv_fwd_with_fused_input_activation(cuda, Cin, Cout, k, stride, H, B, tile):
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    if tile == 6 and Cout % 128:
+        pytest.skip("64x128 tile needs Cout % 128 == 0")
+    L = N.lib()
+    pad = 1 if k == 3 else 0
+    x, sc, sh, w, act64 = _case(cuda, Cin, Cout, k, stride, H, B)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, k, stride, pad)
+    y = torch.full((B, d.Ho, d.Wo, Cout), float("nan"), device=cuda)
+    pb = L.osi_conv_fwd_bnstats_workspace(ctypes.byref(d))
+    ps = torch.full((pb // 4,), float("nan"), device=cuda)
+    P, rows = ctypes.c_int(), ctypes.c_int()
+    N.check(L.osi_conv_fwd_act(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(w), N.ptr(y), tile, N.ptr(ps), pb,
+                               ctypes.byref(P), ctypes.byref(rows), T.S()), "osi_conv_fwd_act")
+    ref = F.conv2d(T.nchw(act64), T.oihw(w.double()), None, stride, pad).permute(0, 2, 3, 1)
+    err = float((y.double() - ref).abs().max())
+    K = Cin * k * k
+    assert err <= (2e-6 + 6e-8 * K ** 0.5) * float(ref.abs().max()) + 1e-6, err
+    # the BatchNorm partials of the epilogue describe this output: merged they give its per-channel mean
+    M = B * d.Ho * d.Wo
+    pm = ps[:P.value * Cout].view(P.value, Cout).double()
+    cnt = torch.full((P.value, 1), float(rows.value), dtype=torch.float64, device=cuda)
+    cnt[-1] = M - (P.value - 1) * rows.value
+    assert torch.allclose((pm * cnt).sum(0) / M, y.double().view(M, Cout).mean(0), atol=1e-5)
+    # without statistics, and the materialised-activation route through the plain kernel agrees to summation-order noise
+    y2 = torch.empty_like(y)
+    N.check(L.osi_conv_fwd_act(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(w), N.ptr(y2), tile, None, 0, None, None, T.S()))
+    assert torch.equal(y2, y)
+    act32 = torch.relu(torch.addcmul(sh, x, sc)).contiguous()
+    y3 = T.conv_fwd(act32, w, k, stride, pad, tile)
+    assert float((y3 - y).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,H,B", SHAPES + [(128, 128, 3, 1, 28, 8), (256, 256, 1, 1, 14, 16)])
+def test_conv_wgrad_with_fused_input_activation(cuda, Cin, Cout, k, stride, H, B):
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    pad = 1 if k == 3 else 0
+    x, sc, sh, w, act64 = _case(cuda, Cin, Cout, k, stride, H, B)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, k, stride, pad)
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(B, d.Ho, d.Wo, Cout, generator=g).to(cuda)
+    nb = L.osi_conv_wgrad_workspace(ctypes.byref(d))
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=cuda)
+    dw = torch.full((Cout, k, k, Cin), float("nan"), device=cuda)
+    N.check(L.osi_conv_wgrad_act(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(dw), N.ptr(ws), nb, T.S()), "osi_conv_wgrad_act")
+    ref = torch.nn.grad.conv2d_weight(T.nchw(act64), (Cout, Cin, k, k), T.nchw(dy.double()), stride, pad).permute(0, 2, 3, 1)
+    Kp = B * d.Ho * d.Wo
+    err = float((dw.double() - ref).abs().max())
+    assert err <= (2e-6 + 6e-8 * Kp ** 0.5) * float(ref.abs().max()) + 1e-6, err
+    # bit-reproducible, and equal (to summation noise) to the plain kernel on the materialised activation
+    dw2 = torch.empty_like(dw)
+    N.check(L.osi_conv_wgrad_act(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(dw2), N.ptr(ws), nb, T.S()))
+    assert torch.equal(dw, dw2)
+    act32 = torch.relu(torch.addcmul(sh, x, sc)).contiguous()
+    assert float((T.conv_wgrad(dy, act32, k, stride, pad) - dw).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+class _Fusion(ctypes.Structure):
+    _fields_ = [("relu_mask", ctypes.c_void_p), ("y0", ctypes.c_void_p), ("mean0", ctypes.c_void_p), ("invstd0", ctypes.c_void_p),
+                ("y1", ctypes.c_void_p), ("mean1", ctypes.c_void_p), ("invstd1", ctypes.c_void_p), ("partials", ctypes.c_void_p),
+                ("partials_bytes", ctypes.c_size_t), ("scale0", ctypes.c_void_p), ("shift0", ctypes.c_void_p)]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,H,B", [(64, 64, 1, 1, 14, 3), (128, 64, 3, 1, 9, 3), (256, 128, 3, 2, 9, 2), (512, 64, 1, 1, 7, 5)])
+def test_dgrad_gate_from_pre_bn_tensor_equals_bitmask(cuda, Cin, Cout, k, stride, H, B):
+    """The fused dgrad epilogue with the ReLU gate recomputed as y0 * scale0 + shift0 > 0 gives exactly the bits of the stored
+    bitmask route (osi_bn_apply_relu_mask evaluates the same fma): masked gradient and BatchNorm partials identical."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    pad = 1 if k == 3 else 0
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, k, stride, pad)
+    M = B * H * H
+    dy = torch.randn(B, d.Ho, d.Wo, Cout, generator=g).to(cuda)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cout * k * k) ** 0.5).to(cuda)
+    y0 = (torch.randn(M, Cin, generator=g) * 2 + 0.3).to(cuda)
+    y0.view(-1)[::97] = 0.0                                               # exact zeros: gate must be off exactly where relu' is 0
+    ga, be = (torch.rand(Cin, generator=g) + 0.5).to(cuda), torch.randn(Cin, generator=g).to(cuda)
+    wsb = max(L.osi_bn_workspace(M, Cin), L.osi_bn_backward_workspace(M, Cin))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    st = [torch.empty(Cin, device=cuda) for _ in range(4)]                # mean, invstd, scale, shift
+    N.check(L.osi_bn_train_stats(N.ptr(y0), M, Cin, N.ptr(ga), N.ptr(be), 1e-5, 0.1, None, None, *[N.ptr(t) for t in st], N.ptr(ws), wsb, T.S()))
+    out = torch.empty(M, Cin, device=cuda)
+    mask = torch.zeros(L.osi_bn_relu_mask_bytes(M, Cin), dtype=torch.uint8, device=cuda)
+    N.check(L.osi_bn_apply_relu_mask(N.ptr(y0), None, N.ptr(st[2]), N.ptr(st[3]), N.ptr(out), N.ptr(mask), M, Cin, T.S()))
+    pb = L.osi_conv_dgrad_fused_workspace(ctypes.byref(d))
+    res = []
+    for use_bits in (True, False):
+        parts = torch.full((pb // 4,), float("nan"), device=cuda)
+        f = _Fusion(mask.data_ptr() if use_bits else None, y0.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), None, None, None,
+                    parts.data_ptr(), pb, None if use_bits else st[2].data_ptr(), None if use_bits else st[3].data_ptr())
+        gbuf = torch.full((B, H, H, Cin), float("nan"), device=cuda)
+        P = ctypes.c_int()
+        N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(gbuf), None, ctypes.byref(f), 0, ctypes.byref(P), T.S()))
+        res.append((gbuf, parts[:2 * P.value * Cin].clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    gate = (out > 0).view(B, H, H, Cin)
+    assert bool((res[1][0][~gate] == 0).all()) and float(res[1][0][gate].abs().sum()) > 0
