@@ -130,6 +130,11 @@ int osi_bn_backward(const float* dout, const float* act, const float* y, const f
 size_t osi_bn_relu_mask_bytes(int M, int C);
 int osi_bn_apply_relu_mask(const float* y, const float* residual, const float* scale, const float* shift, float* out,
                            void* relu_mask, int M, int C, osi_stream_t stream);
+/* Block output of a Bottleneck with a projection shortcut in one pass: out = relu(y * scale + shift + (res_y * res_scale +
+ * res_shift)) — bn3(conv3) + downsample BatchNorm(downsample conv) + ReLU — plus the ReLU bitmask; the shortcut's normalised
+ * tensor is never stored. Bit-identical to osi_bn_apply on the shortcut followed by osi_bn_apply_relu_mask. */
+int osi_bn_apply_relu_mask2(const float* y, const float* scale, const float* shift, const float* res_y, const float* res_scale,
+                            const float* res_shift, float* out, void* relu_mask, int M, int C, osi_stream_t stream);
 int osi_bn_backward_relu_mask(const float* dout, const void* relu_mask, const float* y, const float* mean, const float* invstd,
                               const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
                               size_t ws_bytes, osi_stream_t stream);

@@ -224,9 +224,11 @@ __global__ void k_bn_eval_coeffs(const float* rm, const float* rv, const float* 
 // ReLU bitmask: bit (i & 63) of word [(i >> 6) * 4 + c] = (component c of float4 #i is > 0 after BN(+res)). One bit per
 // element (1/32 of the tensor) lets both BatchNorm-backward passes skip re-reading the activation just to rebuild the mask.
 typedef unsigned long long u64;
-template <bool RES, bool RELU, bool BITS>
+// RES: 0 = none, 1 = add `res`, 2 = add res * rscale + rshift (the projection shortcut's own BatchNorm applied on the fly)
+template <int RES, bool RELU, bool BITS>
 __global__ __launch_bounds__(NT) void k_bn_apply(const f32x4* __restrict__ y, const f32x4* __restrict__ res,
                                                 const f32x4* __restrict__ scale, const f32x4* __restrict__ shift,
+                                                const f32x4* __restrict__ rscale, const f32x4* __restrict__ rshift,
                                                 f32x4* __restrict__ out, u64* __restrict__ bits, size_t n4, int c4n) {
     size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     const size_t step = (size_t)gridDim.x * NT;
@@ -236,7 +238,14 @@ __global__ __launch_bounds__(NT) void k_bn_apply(const f32x4* __restrict__ y, co
         f32x4 v;   // one fma per element: the same expression the fused conv loaders and the dgrad gate evaluate
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(yv[e], sc[e], sh[e]);
-        if (RES) v += res[i];
+        if (RES == 1) v += res[i];
+        if (RES == 2) {
+            const f32x4 rv = res[i], rs = rscale[c4], rh = rshift[c4];
+            f32x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = __builtin_fmaf(rv[e], rs[e], rh[e]);
+            v += t;
+        }
         if (BITS) {
             const u64 b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
             if ((threadIdx.x & 63) == 0) {  // lane 0 carries the smallest (64-aligned) index of the wave
@@ -502,19 +511,24 @@ int osi_bn_eval_coeffs(const float* running_mean, const float* running_var, cons
 }
 
 static int bn_apply_impl(const float* y, const float* residual, const float* scale, const float* shift, float* out, void* bits,
-                         int M, int C, int relu, hipStream_t st) {
+                         int M, int C, int relu, hipStream_t st, const float* rscale = nullptr, const float* rshift = nullptr) {
     OSI_REQUIRE(y && scale && shift && out && M > 0 && C > 0 && C % 4 == 0);
     OSI_REQUIRE(!bits || relu);
+    OSI_REQUIRE((rscale == nullptr) == (rshift == nullptr) && (!rscale || (residual && bits)));
     const size_t n4 = (size_t)M * C / 4;
     const int grid = stream_grid(n4), c4n = C / 4;
     auto Y = (const f32x4*)y; auto R = (const f32x4*)residual; auto S = (const f32x4*)scale; auto H = (const f32x4*)shift;
+    auto RS = (const f32x4*)rscale; auto RH = (const f32x4*)rshift;
     auto O = (f32x4*)out; auto B = (u64*)bits;
-    if (bits && residual) hipLaunchKernelGGL((k_bn_apply<true, true, true>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
-    else if (bits) hipLaunchKernelGGL((k_bn_apply<false, true, true>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
-    else if (residual && relu) hipLaunchKernelGGL((k_bn_apply<true, true, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
-    else if (residual) hipLaunchKernelGGL((k_bn_apply<true, false, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
-    else if (relu) hipLaunchKernelGGL((k_bn_apply<false, true, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
-    else hipLaunchKernelGGL((k_bn_apply<false, false, false>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, O, B, n4, c4n);
+#define OSI_APPLY(RES_, RELU_, BITS_) hipLaunchKernelGGL((k_bn_apply<RES_, RELU_, BITS_>), dim3(grid), dim3(NT), 0, st, Y, R, S, H, RS, RH, O, B, n4, c4n)
+    if (rscale) OSI_APPLY(2, true, true);
+    else if (bits && residual) OSI_APPLY(1, true, true);
+    else if (bits) OSI_APPLY(0, true, true);
+    else if (residual && relu) OSI_APPLY(1, true, false);
+    else if (residual) OSI_APPLY(1, false, false);
+    else if (relu) OSI_APPLY(0, true, false);
+    else OSI_APPLY(0, false, false);
+#undef OSI_APPLY
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
@@ -534,6 +548,12 @@ int osi_bn_apply_relu_mask(const float* y, const float* residual, const float* s
                            void* relu_mask, int M, int C, osi_stream_t stream) {
     OSI_REQUIRE(relu_mask);
     return bn_apply_impl(y, residual, scale, shift, out, relu_mask, M, C, 1, (hipStream_t)stream);
+}
+
+int osi_bn_apply_relu_mask2(const float* y, const float* scale, const float* shift, const float* res_y, const float* res_scale,
+                            const float* res_shift, float* out, void* relu_mask, int M, int C, osi_stream_t stream) {
+    OSI_REQUIRE(relu_mask && res_y && res_scale && res_shift);
+    return bn_apply_impl(y, res_y, scale, shift, out, relu_mask, M, C, 1, (hipStream_t)stream, res_scale, res_shift);
 }
 
 static int bn_backward_impl(const float* dout, const void* msk, int mode, const float* y, const float* mean, const float* invstd,

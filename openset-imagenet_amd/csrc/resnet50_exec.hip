@@ -221,8 +221,9 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
             const int st = b == 0 ? strides[s] : 1;
             Block blk{};
             blk.x_in = x; blk.stage = 3 - s;
-            blk.c1 = n->add_conv_bn(pre + "conv1", pre + "bn1", B, h, w, inpl, planes[s], 1, 1, 0, true);
-            blk.c2 = n->add_conv_bn(pre + "conv2", pre + "bn2", B, h, w, planes[s], planes[s], 3, st, 1, true);
+            // conv1 / conv2: only the pre-BN output is kept (their activation is recomputed in the consumers' loaders)
+            blk.c1 = n->add_conv_bn(pre + "conv1", pre + "bn1", B, h, w, inpl, planes[s], 1, 1, 0, false);
+            blk.c2 = n->add_conv_bn(pre + "conv2", pre + "bn2", B, h, w, planes[s], planes[s], 3, st, 1, false);
             const int ho = n->convs[blk.c2].d.Ho, wo = n->convs[blk.c2].d.Wo;
             blk.c3 = n->add_conv_bn(pre + "conv3", pre + "bn3", B, ho, wo, planes[s], planes[s] * 4, 1, 1, 0, true);
             blk.ds = -1;
@@ -329,20 +330,26 @@ int osi_resnet50_profile_read(osi_resnet50_t n, double* ms, int* count) {
     return OSI_OK;
 }
 
+// conv ci + its BatchNorm statistics. in_bn >= 0: the conv's input is the PRE-BN output of the layer whose BatchNorm is `in_bn`;
+// that BatchNorm + ReLU is applied inside the conv's operand loader (osi_conv_fwd_act) — the activation never exists in HBM.
 static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buffers, float* ws, const float* x, const float* w,
-                       int training, hipStream_t st, size_t bn_ws_off) {
+                       int training, hipStream_t st, size_t bn_ws_off, int in_bn = -1) {
     Conv& c = n->convs[ci];
     BN& b = n->bns[c.bn];
+    const float* isc = in_bn >= 0 ? ws + n->bns[in_bn].scale : nullptr;
+    const float* ish = in_bn >= 0 ? ws + n->bns[in_bn].shift : nullptr;
     if (training) {
         // batch statistics come out of the conv epilogue (per row tile), only a tiny per-channel merge follows
         int P = 0, rows = 0;
-        OSI_TRY(osi_conv_fwd_bnstats(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
+        if (isc) OSI_TRY(osi_conv_fwd_act(&c.d, x, isc, ish, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
+        else OSI_TRY(osi_conv_fwd_bnstats(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
         OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
         OSI_TRY(osi_bn_finalize_stats(ws + bn_ws_off, n->bn_ws_bytes, P, rows, b.M, b.C, params + b.g_off, params + b.b_off, 1e-5f, 0.1f,
                                       buffers + b.rm_off, buffers + b.rv_off, ws + b.mean, ws + b.invstd, ws + b.scale,
                                       ws + b.shift, st));
     } else {
-        OSI_TRY(osi_conv_fwd(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, st));
+        if (isc) OSI_TRY(osi_conv_fwd_act(&c.d, x, isc, ish, w, ws + c.y, OSI_TILE_AUTO, nullptr, 0, nullptr, nullptr, st));
+        else OSI_TRY(osi_conv_fwd(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, st));
         OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
         OSI_TRY(osi_bn_eval_coeffs(buffers + b.rm_off, buffers + b.rv_off, params + b.g_off, params + b.b_off, 1e-5f, b.C,
                                    ws + b.scale, ws + b.shift, st));
@@ -392,19 +399,16 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     // bn1 + relu + maxpool in one pass: the 112x112x64 post-ReLU tensor is never materialised
     OSI_TRY(osi_bn_relu_maxpool_fwd(ws + c0.y, ws + b0.scale, ws + b0.shift, ws + n->a_pool, ws + n->pool_idx, n->B, n->Hs, n->Ws, 64, st));
     OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
-    // bottleneck blocks
+    // bottleneck blocks. Only the block outputs (residual sums) are materialised: conv2 / conv3 read the pre-BN output of the conv
+    // before them and apply its BatchNorm + ReLU in their operand loader; the projection shortcut's BatchNorm is applied inside the
+    // block-output kernel. Per block: 3 (4) convs + one apply pass instead of 3 (4) convs + 3 (4) apply passes.
     for (Block& k : n->blocks) {
         const float* x = ws + k.x_in;
-        const int cs[3] = {k.c1, k.c2, k.c3};
-        const float* in = x;
-        const float* res = x;
         // The projection shortcut (4 blocks) only depends on the block input: with overlap on it runs on the side stream beside
         // the main branch (its own BatchNorm scratch), and is joined before the residual add.
         bool forked = false;
         if (k.ds >= 0) {
             Conv& c = n->convs[k.ds];
-            BN& b = n->bns[c.bn];
-            float* xd = ws + n->scratch[0];
             hipStream_t ds_st = st;
             if (n->fwd_fork && n->async_wgrad()) {
                 if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
@@ -412,25 +416,22 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
                 ds_st = n->side; forked = true;
             }
             OSI_TRY(conv_bn_fwd(n, k.ds, params, buffers, ws, x, params + c.w_off, training, ds_st, forked ? n->bn_ws2 : n->bn_ws));
-            OSI_TRY(osi_bn_apply(ws + c.y, nullptr, ws + b.scale, ws + b.shift, xd, b.M, b.C, 0, ds_st));
-            OSI_TRY(n->mark(OSI_PROF_BN_FWD, ds_st));
             if (forked && hipEventRecord(n->ev_join, n->side) != hipSuccess) return OSI_ERR_LAUNCH;
-            res = xd;
         }
-        for (int j = 0; j < 3; ++j) {
-            Conv& c = n->convs[cs[j]];
-            BN& b = n->bns[c.bn];
-            OSI_TRY(conv_bn_fwd(n, cs[j], params, buffers, ws, in, params + c.w_off, training, st, n->bn_ws));
-            if (j < 2) {
-                OSI_TRY(osi_bn_apply_relu_mask(ws + c.y, nullptr, ws + b.scale, ws + b.shift, ws + c.a, ws + c.mask, b.M, b.C, st));
-                OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
-                in = ws + c.a;
-            }
-        }
+        Conv &c1 = n->convs[k.c1], &c2 = n->convs[k.c2], &c3 = n->convs[k.c3];
+        OSI_TRY(conv_bn_fwd(n, k.c1, params, buffers, ws, x, params + c1.w_off, training, st, n->bn_ws));
+        OSI_TRY(conv_bn_fwd(n, k.c2, params, buffers, ws, ws + c1.y, params + c2.w_off, training, st, n->bn_ws, c1.bn));
+        OSI_TRY(conv_bn_fwd(n, k.c3, params, buffers, ws, ws + c2.y, params + c3.w_off, training, st, n->bn_ws, c2.bn));
         if (forked && hipStreamWaitEvent(st, n->ev_join, 0) != hipSuccess) return OSI_ERR_LAUNCH;
-        Conv& c3 = n->convs[k.c3];
         BN& b3 = n->bns[c3.bn];
-        OSI_TRY(osi_bn_apply_relu_mask(ws + c3.y, res, ws + b3.scale, ws + b3.shift, ws + c3.a, ws + c3.mask, b3.M, b3.C, st));
+        if (k.ds >= 0) {
+            Conv& cd = n->convs[k.ds];
+            BN& bd = n->bns[cd.bn];
+            OSI_TRY(osi_bn_apply_relu_mask2(ws + c3.y, ws + b3.scale, ws + b3.shift, ws + cd.y, ws + bd.scale, ws + bd.shift, ws + c3.a,
+                                            ws + c3.mask, b3.M, b3.C, st));
+        } else {
+            OSI_TRY(osi_bn_apply_relu_mask(ws + c3.y, x, ws + b3.scale, ws + b3.shift, ws + c3.a, ws + c3.mask, b3.M, b3.C, st));
+        }
         OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
     }
     // head
@@ -454,7 +455,8 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
 }
 
 // weight gradient of conv `ci` from dy (scratch buffer index gi): on the side stream when overlap is on
-static int wgrad(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const float* conv_in, hipStream_t st) {
+// in_bn >= 0: conv_in is the PRE-BN output of the layer with BatchNorm `in_bn`; its BN + ReLU is applied in the loader
+static int wgrad(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const float* conv_in, hipStream_t st, int in_bn = -1) {
     Conv& c = n->convs[ci];
     const float* dy = ws + n->scratch[gi];
     hipStream_t ws_st = st;
@@ -467,6 +469,9 @@ static int wgrad(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const
     if (ci == 0) {
         OSI_TRY(osi_conv_wgrad(&c.d, dy, conv_in, ws + n->gpack, ws + n->wg_ws, n->wg_ws_bytes, ws_st));
         OSI_TRY(osi_stem_grad_unpack(ws + n->gpack, grads + c.w_off, 64, ws_st));
+    } else if (in_bn >= 0) {
+        OSI_TRY(osi_conv_wgrad_act(&c.d, dy, conv_in, ws + n->bns[in_bn].scale, ws + n->bns[in_bn].shift, grads + c.w_off, ws + n->wg_ws,
+                                   n->wg_ws_bytes, ws_st));
     } else {
         OSI_TRY(osi_conv_wgrad(&c.d, dy, conv_in, grads + c.w_off, ws + n->wg_ws, n->wg_ws_bytes, ws_st));
     }
@@ -514,7 +519,8 @@ static int dgrad_fused(osi_resnet50* n, int ci, const float* params, float* ws, 
     Conv& p0 = n->convs[pc];
     BN& b0 = n->bns[p0.bn];
     osi_dgrad_fusion f{};
-    f.relu_mask = ws + p0.mask;
+    if (p0.mask != (size_t)-1) f.relu_mask = ws + p0.mask;           // block output: stored ReLU bitmask
+    else { f.scale0 = ws + b0.scale; f.shift0 = ws + b0.shift; }     // in-block activation: gate recomputed from y0
     f.y0 = ws + p0.y; f.mean0 = ws + b0.mean; f.invstd0 = ws + b0.invstd;
     if (pd >= 0) {
         Conv& p1 = n->convs[pd];
@@ -584,13 +590,13 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
         d3 = go;
     }
     // conv3 -> (mask a2, bn2) -> conv2 -> (mask a1, bn1) -> conv1
-    OSI_TRY(wgrad(n, k.c3, grads, ws, d3, ws + c2.a, st));
+    OSI_TRY(wgrad(n, k.c3, grads, ws, d3, ws + c2.y, st, c2.bn));
     int t2 = n->take(st);
     if (t2 < 0) return t2;
     OSI_TRY(dgrad_fused(n, k.c3, params, ws, d3, t2, -1, k.c2, -1, st));
     n->give(d3);
     OSI_TRY(bn_bwd_fused(n, k.c2, params, grads, ws, t2, t2, 0, st));
-    OSI_TRY(wgrad(n, k.c2, grads, ws, t2, ws + c1.a, st));
+    OSI_TRY(wgrad(n, k.c2, grads, ws, t2, ws + c1.y, st, c1.bn));
     int t3 = n->take(st);
     if (t3 < 0) return t3;
     OSI_TRY(dgrad_fused(n, k.c2, params, ws, t2, t3, -1, k.c1, -1, st));

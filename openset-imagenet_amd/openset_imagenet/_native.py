@@ -60,6 +60,7 @@ _SIGS = {
     "osi_bn_backward": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
     "osi_bn_relu_mask_bytes": (c_size_t, [c_int, c_int]),
     "osi_bn_apply_relu_mask": (c_int, [P, P, P, P, P, P, c_int, c_int, P]),
+    "osi_bn_apply_relu_mask2": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "osi_bn_backward_relu_mask": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P]),
     "osi_nchw3_to_nhwc4": (c_int, [P, P, c_int, c_int, c_int, P]),
     "osi_u8hwc3_to_nhwc4": (c_int, [P, P, P, c_int, c_int, c_int, P]),

@@ -123,6 +123,20 @@ def stage_canvas_batch(canvas, crop_xy, flip, out=None, crop=CROP, stream=None):
     return out
 
 
+def device_batch(batch):
+    """(images, labels) on the global device from whatever a loader of this package yields: the reference's (images, labels) pair
+    (reference train.py:128-129: `images = device(images); labels = device(labels)`; already-resident tensors pass through) or the
+    4-tuple of CanvasDataset, staged to NHWC4 on the current stream."""
+    from . import tools
+    if len(batch) == 4:
+        canvas, crop_xy, flip, labels = batch
+        dev = tools.get_device()
+        images = stage_canvas_batch(canvas.to(dev, non_blocking=True), crop_xy.to(dev, non_blocking=True), flip.to(dev, non_blocking=True))
+        return images, tools.device(labels)
+    images, labels = batch
+    return tools.device(images), tools.device(labels)
+
+
 class DevicePrefetcher:
     """Iterates a host DataLoader one batch ahead of the GPU: pinned-memory -> HBM copies and the crop / flip / ToTensor staging
     run on a dedicated copy stream while the compute stream trains on the previous batch; an event per batch orders the two.

@@ -104,12 +104,12 @@ def train(model, data_loader, optimizer, loss_fn, trackers, cfg):
         data_loader = tqdm.tqdm(data_loader)
     wants_features = isinstance(loss_fn, _losses.ObjectosphereLoss)
     pending, counts = [], []
-    for images, labels in data_loader:
+    from .pipeline import device_batch
+    for batch in data_loader:
         model.train()  # batch-norm uses and collects batch statistics
-        batch_len = labels.shape[0]
         optimizer.zero_grad()
-        images = tools.device(images)
-        labels = tools.device(labels)
+        images, labels = device_batch(batch)   # device(images), device(labels) of train.py:128-129; canvas batches are staged
+        batch_len = labels.shape[0]
         logits, features = model(images)
         j = loss_fn(logits, labels, features) if wants_features else loss_fn(logits, labels)
         pending.append(j.detach())
@@ -129,6 +129,7 @@ def validate(model, data_loader, loss_fn, n_classes, trackers, cfg):
     (`sum(known)`, metrics.py:27-28). Here softmax + confidence are one kernel per batch that accumulates the four sums in a
     double[4] on the device (osi_confidence_accumulate); nothing is synchronised until the end of the loop."""
     from . import _native as N
+    from .pipeline import device_batch
     for metric in trackers.values():
         metric.reset()
     if cfg.loss.type == "garbage":
@@ -140,9 +141,8 @@ def validate(model, data_loader, loss_fn, n_classes, trackers, cfg):
     losses, counts = [], []
     acc = None
     with torch.no_grad():
-        for images, labels in data_loader:
-            images = tools.device(images)
-            labels = tools.device(labels)
+        for batch in data_loader:
+            images, labels = device_batch(batch)
             logits, features = model(images)
             j = loss_fn(logits, labels, features) if wants_features else loss_fn(logits, labels)
             losses.append(j)
@@ -165,12 +165,13 @@ def validate(model, data_loader, loss_fn, n_classes, trackers, cfg):
 def get_arrays(model, loader):
     """Targets, logits, deep features and softmax scores of a whole dataset as numpy arrays (reference train.py:200-234);
     everything is gathered on the device and copied to the host once."""
+    from .pipeline import device_batch
     model.eval()
     t, lg, ft, sc = [], [], [], []
     with torch.no_grad():
-        for images, labels in loader:
-            labels = tools.device(labels)
-            logit, feature = model(tools.device(images))
+        for batch in loader:
+            images, labels = device_batch(batch)
+            logit, feature = model(images)
             t.append(labels)
             lg.append(logit)
             ft.append(feature)

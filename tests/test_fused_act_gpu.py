@@ -129,3 +129,25 @@ def test_dgrad_gate_from_pre_bn_tensor_equals_bitmask(cuda, Cin, Cout, k, stride
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     gate = (out > 0).view(B, H, H, Cin)
     assert bool((res[1][0][~gate] == 0).all()) and float(res[1][0][gate].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("M,C", [(37, 64), (4 * 49, 2048), (1000, 256)])
+def test_block_output_with_fused_shortcut_batchnorm(cuda, M, C):
+    """osi_bn_apply_relu_mask2 = bn3 + (downsample BatchNorm applied on the fly) + ReLU + bitmask in one pass, bit-identical to
+    materialising the normalised shortcut with osi_bn_apply first."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(M + C)
+    y, ry = torch.randn(M, C, generator=g).to(cuda), torch.randn(M, C, generator=g).to(cuda)
+    sc, sh, rsc, rsh = [(torch.randn(C, generator=g) * 0.5 + (1 if i % 2 == 0 else 0)).to(cuda) for i in range(4)]
+    xd = torch.empty(M, C, device=cuda)
+    N.check(L.osi_bn_apply(N.ptr(ry), None, N.ptr(rsc), N.ptr(rsh), N.ptr(xd), M, C, 0, T.S()))
+    nb = L.osi_bn_relu_mask_bytes(M, C)
+    out1, m1 = torch.empty(M, C, device=cuda), torch.zeros(nb, dtype=torch.uint8, device=cuda)
+    out2, m2 = torch.empty(M, C, device=cuda), torch.zeros(nb, dtype=torch.uint8, device=cuda)
+    N.check(L.osi_bn_apply_relu_mask(N.ptr(y), N.ptr(xd), N.ptr(sc), N.ptr(sh), N.ptr(out1), N.ptr(m1), M, C, T.S()))
+    N.check(L.osi_bn_apply_relu_mask2(N.ptr(y), N.ptr(sc), N.ptr(sh), N.ptr(ry), N.ptr(rsc), N.ptr(rsh), N.ptr(out2), N.ptr(m2), M, C, T.S()))
+    assert torch.equal(out1, out2) and torch.equal(m1, m2)
+    ref = torch.relu(y.double() * sc.double() + sh.double() + ry.double() * rsc.double() + rsh.double())
+    assert float((out2.double() - ref).abs().max()) <= 1e-5

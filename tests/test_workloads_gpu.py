@@ -167,8 +167,12 @@ def test_hip_model_vs_transformers_witness(cuda, golden_dir):
             p = f"{tag}.{mode}."
             el = float((logits.cpu().double().numpy() - W[p + "logits"]).__abs__().max())
             ef = float((feats.cpu().double().numpy() - W[p + "features"]).__abs__().max())
-            print(f"{p} max|logit - witness|={el:.2e} max|feature - witness|={ef:.2e}")
-            assert el <= LOGIT_TOL and ef <= 2 * LOGIT_TOL
+            # 1e-4 absolute is the north-star bar for logits of magnitude O(1) (train mode: |logit| <= 1.4 here). In eval mode the
+            # randomised running statistics do not match the data and logits reach |237|: there the bar is the same relative
+            # accuracy, 2e-6 of the largest value (torch-CPU fp32 itself is 0.5e-4 .. 1.7e-4 from the fp64 witness on these cases).
+            sl, sf = float(np.abs(W[p + "logits"]).max()), float(np.abs(W[p + "features"]).max())
+            print(f"{p} max|logit - witness|={el:.2e} (max |logit| {sl:.1f})  max|feature - witness|={ef:.2e} (max |feature| {sf:.1f})")
+            assert el <= max(LOGIT_TOL, 2e-6 * sl) and ef <= max(2 * LOGIT_TOL, 2e-6 * sf)
             if mode == "train":
                 st = model.state_dict()
                 for key in W.files:
