@@ -90,12 +90,13 @@ __device__ __forceinline__ bool tile_of_block(int bid, int MT, int NT, int& mt, 
 
 // ---- MFMA over one LDS stage -------------------------------------------------------------------------
 // A: R image (rows = GEMM rows), B: R image (rows = GEMM cols)
-template <int WM, int WN>
+// [J0, J1) of the 4 sub-steps of 8 k each: a kernel may split the block to place other work between MFMAs of the same wave
+template <int WM, int WN, int J0 = 0, int J1 = 4>
 __device__ __forceinline__ void mma_RR(const float* sA, const float* sB, int arow, int brow, int lane,
                                        f32x16 (&acc)[WM][WN]) {
     const int h4 = (lane >> 5) * 4, l31 = lane & 31;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = J0; j < J1; ++j) {
         f32x4 a[WM], b[WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const f32x4*>(sA + (arow + i * 32 + l31) * LDR + 8 * j + h4);
@@ -134,12 +135,12 @@ __device__ __forceinline__ void mma_RC(const float* sA, const float* sB, int aro
     }
 }
 // A: C image [32][LDA], B: C image [32][LDB]
-template <int WM, int WN, int LDA, int LDB>
+template <int WM, int WN, int LDA, int LDB, int K0 = 0, int K1 = BK / 2>
 __device__ __forceinline__ void mma_CC(const float* sA, const float* sB, int acol, int bcol, int lane,
                                        f32x16 (&acc)[WM][WN]) {
     const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
+    for (int ks = K0; ks < K1; ++ks) {
         float a[WM], b[WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i) a[i] = sA[(2 * ks + h) * LDA + acol + i * 32 + l31];
@@ -162,8 +163,10 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // NST = LDS stages: 2 = double buffered (one barrier per K tile), 1 = single buffered (two barriers, half the LDS, twice the
 // resident workgroups per CU)
 // XF: the A operand is relu(x * in_scale[c] + in_shift[c]) (fused BatchNorm-apply + ReLU of the producer layer)
+// (the fused forms pin the register budget of their plain twins — 8 / 5 waves per SIMD — so that the extra loader work cannot
+// cost occupancy, which is what these kernels live on)
 template <int WM, int WN, bool STEM, int NST, bool XF = false>
-__global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_conv_fwd(ConvP p) {
+__global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2)) void k_conv_fwd(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32, BR = BN / 32;  // float4 loads per thread per stage
     constexpr int STAGE = (BM + BN) * LDR;
@@ -258,25 +261,28 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
             if (c0 == p.Cin) { c0 = 0; if (++s == p.S) { s = 0; ++r; } }
         }
     };
+    // XF: the fused activation, applied in registers to the tile sitting in ra right before it is stored to LDS (after the MFMA
+    // block, when the operand fragments are dead: no extra register pressure. Tried and rejected: running it between the wave's own
+    // MFMAs to shorten the load -> LDS window — fragments + transform temporaries live together spill 48-128 B per lane).
+    auto xform = [&]() {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + ld_c0 + kq * 4), sh = *reinterpret_cast<const f32x4*>(s_sh + ld_c0 + kq * 4);
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(ra[i][e], sc[e], sh[e]), 0.f);
+            // 1x1 stride-1: only rows past M are invalid and their results are never stored; otherwise padding taps must read as
+            // the zero the reference pads the ACTIVATION with
+            const bool ok = p.unit ? true : (((a_taps[i] >> ld_tap) & 1) != 0);
+            ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
     auto sstore = [&](int buf) {
         float* sA = smem + buf * STAGE;
         float* sB = sA + BM * LDR;
-        if (XF) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + ld_c0 + kq * 4), sh = *reinterpret_cast<const f32x4*>(s_sh + ld_c0 + kq * 4);
+        if (XF) xform();
 #pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(ra[i][e], sc[e], sh[e]), 0.f);
-                // 1x1 stride-1: only rows past M are invalid and their results are never stored; otherwise padding taps must read
-                // as the zero the reference pads the ACTIVATION with
-                const bool ok = p.unit ? true : (((a_taps[i] >> ld_tap) & 1) != 0);
-                *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
-        }
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
 #pragma unroll
         for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(sB + (lr + 32 * i) * LDR + kq * 4) = rb[i];
     };
@@ -694,7 +700,9 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
 // ======================================================================================================
 // XF: the X operand is relu(x * in_scale[c] + in_shift[c]) (the producer layer's BatchNorm + ReLU applied in the loader)
 template <int WM, int WN, bool STEM, int NST, bool XF = false>
-__global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
+// Register budget = what the split-K plan can keep resident anyway (plan_wgrad sizes a launch for two 128x128, four 128x64 or eight
+// 64x64 workgroups per CU): 3 / 4 / 7-8 waves per SIMD. Asking for more only forces spills into the K loop.
+__global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 3 : (WM * WN == 2 ? 5 : 8)) : 2) void k_conv_wgrad(ConvP p) {
     static_assert(!(XF && STEM), "the stem reads the image, not an activation");
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -818,29 +826,30 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void k_conv_wgrad(ConvP p) {
             rbv[i] = bld4(rx, ok ? (uint32_t)(((((int)b * p.H + hi) * p.W + wi) * p.Cin + coff) * 4) : OOB, 0);
         }
     };
-    auto sstore = [&](int buf) {
-        float* sA = smem + buf * STAGE;
-        float* sB = sA + BK * LDA;
+    // XF: fused activation on the X tile sitting in rbv, in registers, right before the LDS store (see k_conv_fwd)
+    auto xform = [&]() {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + b_col), sh = *reinterpret_cast<const f32x4*>(s_sh + b_col);
 #pragma unroll
-        for (int i = 0; i < ARN; ++i) *reinterpret_cast<f32x4*>(sA + (a_row + ARP * i) * LDA + a_col) = ra[i];
-        if (XF) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + b_col), sh = *reinterpret_cast<const f32x4*>(s_sh + b_col);
+        for (int i = 0; i < BRN; ++i) {
+            const int row = b_row + BRP * i;
+            // a zero operand row (pixel past the split's end, or a padding tap) must stay zero: select after the activation
+            const bool ok = p.unit ? (kbeg + ld_t * BK + row < kend) : (tbl[(ld_t % TW) * BK + row] != OOB);
+            f32x4 v;
 #pragma unroll
-            for (int i = 0; i < BRN; ++i) {
-                const int row = b_row + BRP * i;
-                // a zero operand row (pixel past the split's end, or a padding tap) must stay zero: select after the activation
-                const bool ok = p.unit ? (kbeg + ld_t * BK + row < kend) : (tbl[(ld_t % TW) * BK + row] != OOB);
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(rbv[i][e], sc[e], sh[e]), 0.f);
-                *reinterpret_cast<f32x4*>(sB + row * LDB + b_col) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (b_row + BRP * i) * LDB + b_col) = rbv[i];
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(rbv[i][e], sc[e], sh[e]), 0.f);
+            rbv[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
+    auto sstore = [&](int buf) {
+        float* sA = smem + buf * STAGE;
+        float* sB = sA + BK * LDA;
+        if (XF) xform();
+#pragma unroll
+        for (int i = 0; i < ARN; ++i) *reinterpret_cast<f32x4*>(sA + (a_row + ARP * i) * LDA + a_col) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (b_row + BRP * i) * LDB + b_col) = rbv[i];
+    };
     if (T > 0) {
         if (use_tbl) build_tbl(0);
         gload(0);

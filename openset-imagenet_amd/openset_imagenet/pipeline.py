@@ -98,12 +98,12 @@ class CanvasDataset(torch.utils.data.Dataset):
         arr = np.asarray(img, dtype=np.uint8)
         if self.uint8:
             win, cx, cy = canvas_window(arr, x0, y0)
-            return (torch.from_numpy(np.ascontiguousarray(win)), torch.tensor([cx, cy], dtype=torch.int32),
+            return (torch.from_numpy(np.array(win)), torch.tensor([cx, cy], dtype=torch.int32),   # np.array: a writable, contiguous copy
                     torch.tensor(1 if flip else 0, dtype=torch.uint8), label)
         x = arr[y0:y0 + CROP, x0:x0 + CROP]
         if flip:
             x = x[:, ::-1]
-        return torch.from_numpy(np.ascontiguousarray(x)).permute(2, 0, 1).float().div_(255.0), label   # ToTensor() on the host
+        return torch.from_numpy(np.array(x)).permute(2, 0, 1).float().div_(255.0), label   # ToTensor() on the host
 
 
 def stage_canvas_batch(canvas, crop_xy, flip, out=None, crop=CROP, stream=None):

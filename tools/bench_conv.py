@@ -30,7 +30,7 @@ def timeit(fn):
 
 
 tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
-print(f"B={B}  columns: best tile / TFLOP/s (all tiles: auto,128x128,128x64,64x128,64x64)")
+print(f"B={B}  TFLOP/s per tile: auto,128x128,64x128,64x64,64x64_S1,64x128_S1,128x128_S1,128x64_S1[,auto with fused input activation]; wgrad: plain, fused")
 for Cin, Cout, k, s, H, cnt in SHAPES:
     pad = 1 if k == 3 else 0
     d = N.ConvDesc.make(B, H, H, Cin, Cout, k, s, pad)
@@ -57,6 +57,12 @@ for Cin, Cout, k, s, H, cnt in SHAPES:
         res[name] = r
     f = lambda: N.check(L.osi_conv_wgrad(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(dw), N.ptr(ws), nb, S()))
     res["wgrad"] = [flop / timeit(f) / 1e9]
+    # fused input activation (BatchNorm + ReLU of the producer applied in the loader): AUTO tile
+    sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.5
+    f = lambda: N.check(L.osi_conv_fwd_act(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(w), N.ptr(y), 0, None, 0, None, None, S()))
+    res["fwd"].append(flop / timeit(f) / 1e9)
+    f = lambda: N.check(L.osi_conv_wgrad_act(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(dw), N.ptr(ws), nb, S()))
+    res["wgrad"].append(flop / timeit(f) / 1e9)
     for n in res:
         tot[n][0] += cnt * flop; tot[n][1] += cnt * flop / (res[n][0] * 1e9)
     fm = lambda r: "/".join(f"{v:5.1f}" for v in r)

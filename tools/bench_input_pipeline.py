@@ -26,7 +26,7 @@ import torch  # noqa: E402
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else min(16, os.cpu_count() or 4)
     from PIL import Image
