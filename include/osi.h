@@ -36,7 +36,7 @@ const char* osi_build_arch(void);     /* "gfx950" */
 const char* osi_strerror(int code);
 /* Process-wide development knobs (A/B measurements; the defaults are the measured optimum). Launch functions only READ them and
  * never consult the environment. Names: "wgrad_tile" (64 = force 64x64 weight-gradient tiles), "wgrad_blocks" (split-K footprint
- * budget), "wgrad_nst" (LDS stages, 1|2), "wgrad_group" (XCD co-scheduling of the filter taps, 0|1), "bn_grid" (grid cap of the
+ * budget), "wgrad_nst" (LDS stages, 1|2), "wgrad_group" (weight-gradient block-to-XCD mapping, 0|1|2), "bn_grid" (grid cap of the
  * BatchNorm stream kernels). Unknown name / out-of-range value -> OSI_ERR_ARG. Not meant to be changed while launches are in flight. */
 int osi_set_tuning(const char* name, int value);
 int osi_get_tuning(const char* name, int* value);
@@ -275,6 +275,10 @@ enum { OSI_PROF_START = 0, OSI_PROF_CONV_FWD = 1, OSI_PROF_CONV_DGRAD = 2, OSI_P
        OSI_PROF_BN_BWD = 5, OSI_PROF_OTHER = 6, OSI_PROF_NCLASS = 7 };
 int osi_resnet50_profile(osi_resnet50_t net, int enable);
 int osi_resnet50_profile_read(osi_resnet50_t net, double* ms_per_class, int* ops_per_class);
+/* osi_resnet50_profile(net, 2) = timeline mode: the side-stream overlap stays on and each op's completion event remembers its
+ * stream. timeline_read synchronises, then fills completion times (ms since the first event), classes and stream flags of up to
+ * `cap` ops and resets the log. Dev instrumentation (tools/timeline.py): how far the weight gradients trail the critical path. */
+int osi_resnet50_timeline_read(osi_resnet50_t net, double* t_ms, int* cls, int* on_side, int cap, int* count);
 
 #ifdef __cplusplus
 }

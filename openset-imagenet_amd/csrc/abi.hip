@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*wgrad_group*/ 1};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*wgrad_group*/ 2};
 
 namespace {
 int* tuning_slot(const char* name) {

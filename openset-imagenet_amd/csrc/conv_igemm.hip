@@ -58,7 +58,8 @@ struct ConvP {
     // wgrad only
     int kchunk;       // pixels per split
     int wtbl;         // generic loader: rolling table of input byte offsets in LDS instead of per-row divisions
-    int wgroup, splits;  // XCD-aware (cell, tap) block mapping on a 1-D grid; number of K splits
+    int wgroup, splits;  // XCD-aware block mapping on a 1-D grid; number of K splits
+    int gkind, gkeys, ginner;  // what an XCD's consecutive slots share (see k_conv_wgrad), number of keys, workgroups per key
     // fused input activation (fwd A operand / wgrad X operand): the operand is relu(x * in_scale[c] + in_shift[c]) — the BatchNorm +
     // ReLU of the producer layer applied in the loader, so the activation tensor is never materialised. Zero padding / rows past
     // the end stay exact zeros (the select runs AFTER the activation).
@@ -716,19 +717,24 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 3 : (WM * WN == 2 ?
     // tiles: rows over cout (MT), cols over (tap, cin tile) (NT), K splits
     int mt, ntile, split;
     if (p.wgroup) {
-        // XCD-aware cell mapping: the R*S tap workgroups of one (cout tile, cin tile, K split) cell read the SAME dY chunk and
-        // overlapping windows of the same X chunk. Workgroups b and b+8 share an XCD, so the taps of a cell take consecutive
-        // dispatch slots of one XCD: the first one pulls the chunk from HBM, the others hit that XCD's L2.
+        // XCD-aware mapping on a 1-D grid. Workgroups b and b+8 share an XCD (and its L2); the workgroups that read the same bytes
+        // take CONSECUTIVE dispatch slots of ONE XCD, so the first pulls a chunk over the fabric and the others hit that L2:
+        //   gkind 0 (splits >= 8)  key = K split:          all (cout tile, cin tile, tap) workgroups of a split share its dY and X chunks
+        //   gkind 1                key = (split, cout tile): its (cin tile, tap) workgroups share the dY tile
+        //   gkind 2                key = (split, cin tile):  its (cout tile, tap) workgroups share the X slice
+        //   gkind 3                key = (split, cout tile, cin tile): only the R*S taps of a cell share (dY tile, X windows)
         const int taps = STEM ? 1 : p.R * p.S;
         const int ctiles = p.NT / taps;
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int tp = slot % taps;
-        const int cell = (slot / taps) * 8 + xcd;
-        if (cell >= p.MT * ctiles * p.splits) return;
-        mt = cell % p.MT;
-        const int rest = cell / p.MT;
-        const int ct = rest % ctiles;
-        split = rest / ctiles;
+        const int u = slot % p.ginner;
+        const int key = (slot / p.ginner) * 8 + xcd;
+        if (key >= p.gkeys) return;
+        const int tp = u % taps, v = u / taps;
+        int ct;
+        if (p.gkind == 0) { split = key; mt = v % p.MT; ct = v / p.MT; }
+        else if (p.gkind == 1) { split = key / p.MT; mt = key - split * p.MT; ct = v; }
+        else if (p.gkind == 2) { split = key / ctiles; ct = key - split * ctiles; mt = v; }
+        else { mt = key % p.MT; const int rest = key / p.MT; ct = rest % ctiles; split = rest / ctiles; }
         ntile = tp * ctiles + ct;
     } else {
         mt = blockIdx.x % p.MT; ntile = blockIdx.x / p.MT; split = blockIdx.y;
@@ -1013,11 +1019,21 @@ static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
     if (XF) smem += 2 * BN * sizeof(float);                 // scale | shift of the column tile's channels
     if (int e = set_smem(k_conv_wgrad<WM, WN, STEM, NST, XF>, smem)) return e;
     p.splits = splits;
-    p.wgroup = (g_osi_tuning.wgrad_group != 0) ? 1 : 0;
+    p.wgroup = g_osi_tuning.wgrad_group;   // 0: 2-D grid, 1: only the taps of a cell share an XCD, 2 (default): whole K splits do
     if (p.wgroup) {
         const int taps = STEM ? 1 : p.R * p.S;
-        const long cells = (long)p.MT * (p.NT / taps) * splits;
-        const long grid = (cells + 7) / 8 * 8 * taps;
+        const int ctiles = p.NT / taps;
+        if (p.wgroup == 1) { p.gkind = 3; p.gkeys = p.MT * ctiles * splits; p.ginner = taps; }
+        else if (splits >= 8) { p.gkind = 0; p.gkeys = splits; p.ginner = p.MT * ctiles * taps; }
+        else {
+            // few splits (many output tiles): spread (split, tile-row) or (split, tile-column) keys over the XCDs, whichever
+            // re-reads fewer bytes across XCDs: rows share the dY tile and re-read X once per cout tile, columns the other way round
+            const double dy_bytes = (double)p.Cout, x_bytes = (double)p.Cin * (STEM ? 1 : 1);   // per pixel, up to a common factor
+            const double cost_rows = x_bytes * (p.MT < 8 ? p.MT : 8) + dy_bytes, cost_cols = dy_bytes * (ctiles < 8 ? ctiles : 8) + x_bytes;
+            if (cost_rows <= cost_cols) { p.gkind = 1; p.gkeys = splits * p.MT; p.ginner = ctiles * taps; }
+            else { p.gkind = 2; p.gkeys = splits * ctiles; p.ginner = p.MT * taps; }
+        }
+        const long grid = ((long)p.gkeys + 7) / 8 * 8 * p.ginner;
         hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST, XF>), dim3((unsigned)grid), dim3(256), smem, st, p);
     } else {
         hipLaunchKernelGGL((k_conv_wgrad<WM, WN, STEM, NST, XF>), dim3(p.MT * p.NT, splits), dim3(256), smem, st, p);
@@ -1051,6 +1067,12 @@ static WgradPlan plan_wgrad(const osi_conv_desc* d) {
     long maxs = (M + 8 * BK - 1) / (8 * BK);                // at least 8 K tiles per split (amortises the 64 KiB slab tile)
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
+    // whole splits are dealt to the 8 XCDs (k_conv_wgrad's mapping): a multiple of 8 gives every XCD the same number of them
+    if (g_osi_tuning.wgrad_group == 2 && splits >= 8) {
+        long r8 = (splits + 4) / 8 * 8;
+        if (r8 > maxs) r8 = maxs / 8 * 8;
+        if (r8 >= 8) splits = r8;
+    }
     long chunk = ((M + splits - 1) / splits + BK - 1) / BK * BK;
     splits = (M + chunk - 1) / chunk;
     w.splits = (int)splits; w.kchunk = (int)chunk;

@@ -82,6 +82,8 @@ struct osi_resnet50 {
     std::vector<int> free_list;
     // optional HIP-event instrumentation: one event after every op, tagged with the op's class
     bool prof_on = false;
+    bool prof_timeline = false;      // mode 2: keep the side-stream overlap, record where each op ran (osi_resnet50_timeline_read)
+    std::vector<int> prof_side;      // per event: 1 = recorded on the side stream
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_cls;
     int prof_n = 0;
@@ -90,9 +92,10 @@ struct osi_resnet50 {
         if (prof_n == (int)prof_ev.size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return OSI_ERR_LAUNCH;
-            prof_ev.push_back(e); prof_cls.push_back(0);
+            prof_ev.push_back(e); prof_cls.push_back(0); prof_side.push_back(0);
         }
         prof_cls[prof_n] = cls;
+        prof_side[prof_n] = (side != nullptr && st == side) ? 1 : 0;
         if (hipEventRecord(prof_ev[prof_n], st) != hipSuccess) return OSI_ERR_LAUNCH;
         ++prof_n;
         return OSI_OK;
@@ -161,7 +164,7 @@ struct osi_resnet50 {
             if (hipEventCreateWithFlags(&buf_ev[i], hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
         return OSI_OK;
     }
-    bool async_wgrad() const { return overlap && !prof_on && side != nullptr; }
+    bool async_wgrad() const { return overlap && (!prof_on || prof_timeline) && side != nullptr; }
     // a scratch buffer may only be rewritten on `st` after its last side-stream reader has finished
     // returns the buffer index, or a negative OSI_ERR_* code
     int take(hipStream_t st) {
@@ -310,6 +313,25 @@ int osi_resnet50_stage_grad_range(osi_resnet50_t net, int s, size_t* lo, size_t*
 int osi_resnet50_profile(osi_resnet50_t n, int enable) {
     OSI_REQUIRE(n);
     n->prof_on = enable != 0;
+    n->prof_timeline = enable == 2;
+    n->prof_n = 0;
+    return OSI_OK;
+}
+// Timeline mode (osi_resnet50_profile(net, 2)): the overlapped schedule is kept and every op's completion event carries the stream
+// it ran on. Host-synchronising read-out: t_ms[i] = completion time of op i relative to the first recorded event.
+int osi_resnet50_timeline_read(osi_resnet50_t n, double* t_ms, int* cls, int* on_side, int cap, int* count) {
+    OSI_REQUIRE(n && t_ms && cls && on_side && count && cap > 0);
+    *count = 0;
+    if (n->prof_n == 0) return OSI_OK;
+    for (int i = 0; i < n->prof_n; ++i)
+        if (hipEventSynchronize(n->prof_ev[i]) != hipSuccess) return OSI_ERR_LAUNCH;
+    const int m = n->prof_n < cap ? n->prof_n : cap;
+    for (int i = 0; i < m; ++i) {
+        float t = 0.f;
+        if (i > 0 && hipEventElapsedTime(&t, n->prof_ev[0], n->prof_ev[i]) != hipSuccess) return OSI_ERR_LAUNCH;
+        t_ms[i] = t; cls[i] = n->prof_cls[i]; on_side[i] = n->prof_side[i];
+    }
+    *count = m;
     n->prof_n = 0;
     return OSI_OK;
 }
@@ -387,7 +409,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     const float* x4 = (!image && ext) ? ext : ws + n->x4;
     n->x4_cur = x4;
     n->fwd_done = false;
-    if (training && n->overlap && !n->prof_on) OSI_TRY(n->ensure_side());
+    if (training && n->overlap && (!n->prof_on || n->prof_timeline)) OSI_TRY(n->ensure_side());
     OSI_TRY(n->mark(OSI_PROF_START, st));
     // stem
     if (image) OSI_TRY(osi_nchw3_to_nhwc4(image, ws + n->x4, n->B, n->H, n->W, st));
@@ -480,7 +502,7 @@ static int wgrad(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const
         n->buf_pending[gi] = true;
         n->side_dirty = true;
     }
-    OSI_TRY(n->mark(OSI_PROF_CONV_WGRAD, st));
+    OSI_TRY(n->mark(OSI_PROF_CONV_WGRAD, ws_st));
     return OSI_OK;
 }
 
@@ -630,7 +652,7 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     auto S = [&](int i) { return ws + n->scratch[i]; };
-    if (n->overlap && !n->prof_on) OSI_TRY(n->ensure_side());
+    if (n->overlap && (!n->prof_on || n->prof_timeline)) OSI_TRY(n->ensure_side());
     OSI_TRY(n->mark(OSI_PROF_START, st));
 
     for (int stage = stage_lo; stage < stage_hi; ++stage) {

@@ -427,7 +427,7 @@ def test_conv_epilogue_batchnorm_statistics(cuda, Cin, Cout, k, stride, H, B):
 class _Fusion(ctypes.Structure):
     _fields_ = [("relu_mask", ctypes.c_void_p), ("y0", ctypes.c_void_p), ("mean0", ctypes.c_void_p), ("invstd0", ctypes.c_void_p),
                 ("y1", ctypes.c_void_p), ("mean1", ctypes.c_void_p), ("invstd1", ctypes.c_void_p), ("partials", ctypes.c_void_p),
-                ("partials_bytes", ctypes.c_size_t)]
+                ("partials_bytes", ctypes.c_size_t), ("scale0", ctypes.c_void_p), ("shift0", ctypes.c_void_p)]   # osi_dgrad_fusion (ABI 2)
 
 
 @pytest.mark.parametrize("Cin,Cout,k,stride,H,B,two", [(64, 64, 1, 1, 14, 3, False), (128, 64, 3, 1, 9, 3, True), (256, 128, 3, 2, 9, 2, False),
@@ -473,7 +473,7 @@ def test_dgrad_fused_epilogue_vs_unfused(cuda, Cin, Cout, k, stride, H, B, two):
     parts = torch.full((pb // 4,), float("nan"), device=cuda)
     f = _Fusion(mask.data_ptr(), ys[0].data_ptr(), stats[0][0].data_ptr(), stats[0][1].data_ptr(),
                 ys[1].data_ptr() if two else None, stats[1][0].data_ptr() if two else None, stats[1][1].data_ptr() if two else None,
-                parts.data_ptr(), pb)
+                parts.data_ptr(), pb, None, None)
     gbuf = torch.full((B, H, H, Cin), float("nan"), device=cuda)
     P = ctypes.c_int()
     N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(gbuf), N.ptr(addend), ctypes.byref(f), 0, ctypes.byref(P), T.S()))
