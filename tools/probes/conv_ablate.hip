@@ -1,0 +1,185 @@
+// Dev probe (GPU box): where does the 64x64 single-buffered fp32-MFMA tile loop lose its time?
+// A GEMM-shaped copy of k_conv_fwd's 1x1 path (Y[M][N] = X[M][K] * W[N][K]^T, 4 waves of 32x32, BK = 32, buffer loads ->
+// registers -> LDS R images -> ds_read_b128 -> v_mfma_f32_32x32x2_f32) with the loop's ingredients removed one at a time:
+//   V0 full loop        V1 no global loads in the loop     V2 loads issued but never stored to LDS
+//   V3 no barriers      V4 MFMA + LDS reads only           V5 MFMA only (operands in registers: the bare matrix-pipe rate)
+//   V6 full loop, loads two tiles ahead (register double buffer)
+//   V7 MFMA only with v_mfma_f32_16x16x4_f32 (4 independent 16x16 accumulators per wave, same FLOPs per cycle on paper)
+//   V8 full loop on 16x16x4 (K order permuted inside each 16-k chunk so that one ds_read_b128 still feeds four MFMAs)
+// Results are wrong for V1..V5 by construction; only the timing matters. Every variant keeps its inputs alive through asm volatile.
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/conv_ablate.hip -o /tmp/conv_ablate && /tmp/conv_ablate
+#pragma clang diagnostic ignored "-Wunused-value"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int BK = 32, LDR = BK + 4;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+template <int V>
+__global__ __launch_bounds__(256, V == 6 ? 6 : 8) void k_gemm(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int M,
+                                                int N, int K, int MT, int NT) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int nt = slot % NT, mt = (slot / NT) * 8 + xcd;
+    if (mt >= MT) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = mt * 64, n0 = nt * 64, kq = tid & 7, lr = tid >> 3;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(X, M * K * 4), rw = make_rsrc(W, N * K * 4);
+    uint32_t a_off[2], b_off[2];
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + lr + 32 * i;
+        a_off[i] = m < M ? (uint32_t)((m * K + kq * 4) * 4) : 0x80000000u;
+        b_off[i] = (uint32_t)(((n0 + lr + 32 * i) * K + kq * 4) * 4);
+    }
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4v acc4[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc4[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int T = K / BK;
+    f32x4 ra[2], rb[2], ra2[2], rb2[2];
+    auto gload = [&](int t, f32x4 (&a)[2], f32x4 (&b)[2]) {
+        for (int i = 0; i < 2; ++i) { a[i] = bld4(rx, a_off[i], (uint32_t)(t * BK * 4)); b[i] = bld4(rw, b_off[i], (uint32_t)(t * BK * 4)); }
+    };
+    auto sstore = [&](f32x4 (&a)[2], f32x4 (&b)[2]) {
+        float* sA = smem; float* sB = sA + 64 * LDR;
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = a[i];
+            *reinterpret_cast<f32x4*>(sB + (lr + 32 * i) * LDR + kq * 4) = b[i];
+        }
+    };
+    auto mma = [&]() {
+        const float* sA = smem; const float* sB = sA + 64 * LDR;
+        const int h4 = (lane >> 5) * 4, l31 = lane & 31;
+        if (V == 7 || V == 8) {
+            // 16x16x4: lane (r = lane & 15, g = lane >> 4) supplies k = 4g + e to MFMA e of a 16-k chunk (same permutation for A and B)
+            const int r15 = lane & 15, g4 = (lane >> 4) * 4;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {            // two 16-k chunks per 32-k tile
+                f32x4 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (V == 7) { a[i] = ra[i]; b[i] = rb[i]; }
+                    else {
+                        a[i] = *reinterpret_cast<const f32x4*>(sA + (wm * 32 + 16 * i + r15) * LDR + 16 * c + g4);
+                        b[i] = *reinterpret_cast<const f32x4*>(sB + (wn * 32 + 16 * i + r15) * LDR + 16 * c + g4);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc4[i][j], 0, 0, 0);
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 a, b;
+            if (V == 5) { a = ra[0]; b = rb[0]; }
+            else {
+                a = *reinterpret_cast<const f32x4*>(sA + (wm * 32 + l31) * LDR + 8 * j + h4);
+                b = *reinterpret_cast<const f32x4*>(sB + (wn * 32 + l31) * LDR + 8 * j + h4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        }
+    };
+    gload(0, ra, rb);
+    sstore(ra, rb);
+    __syncthreads();
+    if (V == 6) {
+        if (T > 1) gload(1, ra, rb);
+        for (int t = 0; t < T; t += 2) {       // two tiles per trip: ra/rb hold t+1, ra2/rb2 receive t+2
+            if (t + 2 < T) gload(t + 2, ra2, rb2);
+            mma();
+            __syncthreads();
+            if (t + 1 < T) sstore(ra, rb);
+            __syncthreads();
+            if (t + 1 >= T) break;
+            if (t + 3 < T) gload(t + 3, ra, rb);
+            mma();
+            __syncthreads();
+            if (t + 2 < T) sstore(ra2, rb2);
+            __syncthreads();
+        }
+    } else {
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T && (V == 0 || V == 2 || V == 3 || V == 8)) gload(t + 1, ra, rb);
+            mma();
+            if (V != 3 && V != 4 && V != 5 && V != 7) __syncthreads();
+            if (t + 1 < T) {
+                if (V == 0 || V == 1 || V == 3 || V == 8) sstore(ra, rb);
+                if (V == 2) asm volatile("" ::"v"(ra[0]), "v"(ra[1]), "v"(rb[0]), "v"(rb[1]));   // loads stay live (and waited for)
+            }
+            if (V != 3 && V != 4 && V != 5 && V != 7) __syncthreads();
+        }
+    }
+    if (V == 7 || V == 8) {     // fold the four 16x16 accumulators into the store pattern below (layout irrelevant for timing)
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 4; ++r) acc[(i * 2 + j) * 4 + r] = acc4[i][j][r];
+    }
+    // epilogue as in the product kernel's generic path (enough to keep the accumulators alive)
+    const int col = n0 + wn * 32 + (lane & 31);
+    for (int r = 0; r < 16; ++r) {
+        int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M) Y[(size_t)m * N + col] = acc[r];
+    }
+}
+
+template <int V>
+static float run(const float* X, const float* W, float* Y, int M, int N, int K, int reps) {
+    const int MT = (M + 63) / 64, NT = N / 64;
+    const int grid = (MT + 7) / 8 * 8 * NT;
+    const size_t smem = (size_t)128 * LDR * sizeof(float);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_gemm<V>), dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_gemm<V>), dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
+int main() {
+    struct Shape { int M, N, K; const char* what; };
+    const Shape shapes[] = {{100352, 128, 512, "512->128 1x1 @28 (B=128)"}, {25088, 256, 2304, "256->256 3x3 @14 as GEMM"},
+                            {401408, 256, 64, "64->256 1x1 @56"}, {25088, 1024, 256, "256->1024 1x1 @14"},
+                            {6272, 512, 4608, "512->512 3x3 @7 as GEMM"}};
+    for (const Shape& s : shapes) {
+        float *X, *W, *Y;
+        hipMalloc(&X, (size_t)s.M * s.K * 4); hipMalloc(&W, (size_t)s.N * s.K * 4); hipMalloc(&Y, (size_t)s.M * s.N * 4);
+        std::vector<float> h((size_t)s.M * s.K);
+        for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+        hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(W, h.data(), (size_t)s.N * s.K * 4, hipMemcpyHostToDevice);
+        const double gflop = 2.0 * s.M * s.N * s.K / 1e9;
+        printf("%-28s M=%d N=%d K=%d  (%d workgroups, %.2f per CU)\n", s.what, s.M, s.N, s.K, (s.M + 63) / 64 * (s.N / 64),
+               (s.M + 63) / 64 * (s.N / 64) / 256.0);
+        for (int round = 0; round < 2; ++round) {
+            float t7 = run<7>(X, W, Y, s.M, s.N, s.K, 10), t8 = run<8>(X, W, Y, s.M, s.N, s.K, 10);
+            float t[7] = {run<0>(X, W, Y, s.M, s.N, s.K, 10), run<1>(X, W, Y, s.M, s.N, s.K, 10), run<2>(X, W, Y, s.M, s.N, s.K, 10),
+                          run<3>(X, W, Y, s.M, s.N, s.K, 10), run<4>(X, W, Y, s.M, s.N, s.K, 10), run<5>(X, W, Y, s.M, s.N, s.K, 10),
+                          run<6>(X, W, Y, s.M, s.N, s.K, 10)};
+            printf("  round %d TFLOP/s: full %.1f | no-gload %.1f | no-lds-store %.1f | no-barrier %.1f | mfma+ldsread %.1f | mfma-only %.1f | 2-ahead %.1f | 16x16x4 mfma-only %.1f | 16x16x4 full %.1f\n",
+                   round, gflop / t[0], gflop / t[1], gflop / t[2], gflop / t[3], gflop / t[4], gflop / t[5], gflop / t[6], gflop / t7, gflop / t8);
+        }
+        hipFree(X); hipFree(W); hipFree(Y);
+    }
+    return 0;
+}
