@@ -2,8 +2,9 @@
 
     python tools/bench_input_pipeline.py [n_images] [batch] [workers]
 
-Writes n JPEG files (ImageNet-like sizes around 500x375, random content — decode cost is what matters, not the pixels), a
-protocol CSV, and times one epoch of openset_imagenet.train.train() three ways:
+Writes up to 1024 JPEG files (ImageNet-like sizes around 500x375 — decode cost is what matters, not the pixels), a protocol CSV of
+n rows cycling over them (an epoch must be long enough to amortise the ~0.5 s the workers need to fill the pipeline at its start),
+and times one epoch of openset_imagenet.train.train() three ways:
 
   reference-style   fp32 CHW samples produced on the host workers (decode, Resize(256), crop, flip, ToTensor — the reference's
                     transform, train.py:259-263), default-collated, copied inside the step (train.py:128)
@@ -26,7 +27,7 @@ import torch  # noqa: E402
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else min(16, os.cpu_count() or 4)
     from PIL import Image
@@ -39,11 +40,13 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         rows = []
         base = rng.integers(0, 256, size=(48, 64, 3), dtype=np.uint8)
-        for i in range(n):
+        n_files = min(n, 1024)
+        for i in range(n_files):
             w, h = int(rng.integers(400, 600)), int(rng.integers(300, 450))
             img = Image.fromarray(base).resize((w, h), Image.BICUBIC)       # smooth content: realistic JPEG entropy
             img.save(os.path.join(d, f"{i}.jpg"), quality=90)
-            rows.append(f"{i}.jpg,{-1 if i % 3 == 0 else i % C}")
+        for i in range(n):
+            rows.append(f"{i % n_files}.jpg,{-1 if i % 3 == 0 else i % C}")
         csv = os.path.join(d, "p2_train.csv")
         open(csv, "w").write("\n".join(rows) + "\n")
 
@@ -81,6 +84,7 @@ def main():
         out = {"images": n, "batch": B, "workers": workers, "host_cpus": os.cpu_count()}
         ref, canv = loader(False), loader(True)
         epoch(canv)                                  # warm-up: worker start-up, kernels, allocator
+        out["jpeg_files"] = n_files
         out["loader_only_reference_fp32_img_s"] = round(epoch(ref, False), 1)
         out["loader_only_canvas_u8_img_s"] = round(epoch(canv, False), 1)
         out["train_reference_style_img_s"] = round(epoch(ref), 1)
