@@ -1028,7 +1028,7 @@ static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
         else {
             // few splits (many output tiles): spread (split, tile-row) or (split, tile-column) keys over the XCDs, whichever
             // re-reads fewer bytes across XCDs: rows share the dY tile and re-read X once per cout tile, columns the other way round
-            const double dy_bytes = (double)p.Cout, x_bytes = (double)p.Cin * (STEM ? 1 : 1);   // per pixel, up to a common factor
+            const double dy_bytes = (double)p.Cout, x_bytes = (double)p.Cin;   // bytes per pixel of the two operands, up to a common factor
             const double cost_rows = x_bytes * (p.MT < 8 ? p.MT : 8) + dy_bytes, cost_cols = dy_bytes * (ctiles < 8 ? ctiles : 8) + x_bytes;
             if (cost_rows <= cost_cols) { p.gkind = 1; p.gkeys = splits * p.MT; p.ginner = ctiles * taps; }
             else { p.gkind = 2; p.gkeys = splits * ctiles; p.ginner = p.MT * taps; }

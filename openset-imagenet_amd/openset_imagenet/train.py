@@ -215,10 +215,7 @@ def worker(cfg):
 
     `cfg.data.synthetic` (new key, default absent) = number of synthetic training samples to use instead of the CSV files."""
     import logging
-    import time
     import torch.distributed as dist
-    from .dataset import LabelTable, SyntheticImagenet
-    from .pipeline import DevicePrefetcher
     set_seeds(cfg.seed)
     rank, world, local_rank = dist_env()
     distributed = world > 1

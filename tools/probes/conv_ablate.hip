@@ -139,6 +139,71 @@ __global__ __launch_bounds__(256, V == 6 ? 6 : 8) void k_gemm(const float* __res
     }
 }
 
+// V9: the full loop on a 32 (M) x 64 (N) tile with TWO waves (128 threads): twice the workgroups of the 64x64 form for the layers
+// that have only 3-6 of those per CU (14x14 and 7x7 spatial sizes), at 1.5x the operand traffic per FLOP.
+__global__ __launch_bounds__(128, 8) void k_gemm_32x64(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int M,
+                                                      int N, int K, int MT, int NT) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int nt = slot % NT, mt = (slot / NT) * 8 + xcd;
+    if (mt >= MT) return;
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int m0 = mt * 32, n0 = nt * 64, kq = tid & 7, lr = tid >> 3;      // 16 rows per pass
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(X, M * K * 4), rw = make_rsrc(W, N * K * 4);
+    uint32_t a_off[2], b_off[4];
+    for (int i = 0; i < 2; ++i) { int m = m0 + lr + 16 * i; a_off[i] = m < M ? (uint32_t)((m * K + kq * 4) * 4) : 0x80000000u; }
+    for (int i = 0; i < 4; ++i) b_off[i] = (uint32_t)(((n0 + lr + 16 * i) * K + kq * 4) * 4);
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int T = K / BK;
+    f32x4 ra[2], rb[4];
+    float* sA = smem; float* sB = sA + 32 * LDR;
+    auto gload = [&](int t) {
+        for (int i = 0; i < 2; ++i) ra[i] = bld4(rx, a_off[i], (uint32_t)(t * BK * 4));
+        for (int i = 0; i < 4; ++i) rb[i] = bld4(rw, b_off[i], (uint32_t)(t * BK * 4));
+    };
+    auto sstore = [&]() {
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 16 * i) * LDR + kq * 4) = ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(sB + (lr + 16 * i) * LDR + kq * 4) = rb[i];
+    };
+    gload(0); sstore(); __syncthreads();
+    const int h4 = (lane >> 5) * 4, l31 = lane & 31;
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) gload(t + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sA + l31 * LDR + 8 * j + h4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sB + (wn * 32 + l31) * LDR + 8 * j + h4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (t + 1 < T) sstore();
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    for (int r = 0; r < 16; ++r) {
+        int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M) Y[(size_t)m * N + col] = acc[r];
+    }
+}
+static float run9(const float* X, const float* W, float* Y, int M, int N, int K, int reps) {
+    const int MT = (M + 31) / 32, NT = N / 64;
+    const int grid = (MT + 7) / 8 * 8 * NT;
+    const size_t smem = (size_t)96 * LDR * sizeof(float);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_gemm_32x64, dim3(grid), dim3(128), smem, 0, X, W, Y, M, N, K, MT, NT);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_gemm_32x64, dim3(grid), dim3(128), smem, 0, X, W, Y, M, N, K, MT, NT);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
 template <int V>
 static float run(const float* X, const float* W, float* Y, int M, int N, int K, int reps) {
     const int MT = (M + 63) / 64, NT = N / 64;
@@ -160,7 +225,8 @@ int main() {
     struct Shape { int M, N, K; const char* what; };
     const Shape shapes[] = {{100352, 128, 512, "512->128 1x1 @28 (B=128)"}, {25088, 256, 2304, "256->256 3x3 @14 as GEMM"},
                             {401408, 256, 64, "64->256 1x1 @56"}, {25088, 1024, 256, "256->1024 1x1 @14"},
-                            {6272, 512, 4608, "512->512 3x3 @7 as GEMM"}};
+                            {6272, 512, 4608, "512->512 3x3 @7 as GEMM"}, {25088, 256, 1024, "1024->256 1x1 @14"},
+                            {6272, 512, 2048, "2048->512 1x1 @7"}};
     for (const Shape& s : shapes) {
         float *X, *W, *Y;
         hipMalloc(&X, (size_t)s.M * s.K * 4); hipMalloc(&W, (size_t)s.N * s.K * 4); hipMalloc(&Y, (size_t)s.M * s.N * 4);
@@ -172,12 +238,12 @@ int main() {
         printf("%-28s M=%d N=%d K=%d  (%d workgroups, %.2f per CU)\n", s.what, s.M, s.N, s.K, (s.M + 63) / 64 * (s.N / 64),
                (s.M + 63) / 64 * (s.N / 64) / 256.0);
         for (int round = 0; round < 2; ++round) {
-            float t7 = run<7>(X, W, Y, s.M, s.N, s.K, 10), t8 = run<8>(X, W, Y, s.M, s.N, s.K, 10);
+            float t7 = run<7>(X, W, Y, s.M, s.N, s.K, 10), t8 = run<8>(X, W, Y, s.M, s.N, s.K, 10), t9 = run9(X, W, Y, s.M, s.N, s.K, 10);
             float t[7] = {run<0>(X, W, Y, s.M, s.N, s.K, 10), run<1>(X, W, Y, s.M, s.N, s.K, 10), run<2>(X, W, Y, s.M, s.N, s.K, 10),
                           run<3>(X, W, Y, s.M, s.N, s.K, 10), run<4>(X, W, Y, s.M, s.N, s.K, 10), run<5>(X, W, Y, s.M, s.N, s.K, 10),
                           run<6>(X, W, Y, s.M, s.N, s.K, 10)};
-            printf("  round %d TFLOP/s: full %.1f | no-gload %.1f | no-lds-store %.1f | no-barrier %.1f | mfma+ldsread %.1f | mfma-only %.1f | 2-ahead %.1f | 16x16x4 mfma-only %.1f | 16x16x4 full %.1f\n",
-                   round, gflop / t[0], gflop / t[1], gflop / t[2], gflop / t[3], gflop / t[4], gflop / t[5], gflop / t[6], gflop / t7, gflop / t8);
+            printf("  round %d TFLOP/s: full %.1f | no-gload %.1f | no-lds-store %.1f | no-barrier %.1f | mfma+ldsread %.1f | mfma-only %.1f | 2-ahead %.1f | 16x16x4 mfma-only %.1f | 16x16x4 full %.1f | 32x64 tile, 2 waves %.1f\n",
+                   round, gflop / t[0], gflop / t[1], gflop / t[2], gflop / t[3], gflop / t[4], gflop / t[5], gflop / t[6], gflop / t7, gflop / t8, gflop / t9);
         }
         hipFree(X); hipFree(W); hipFree(Y);
     }
