@@ -66,6 +66,13 @@ int osi_conv_fwd_bnstats(const osi_conv_desc* d, const float* x, const float* w,
  * (then P / rows_per_block are ignored); tiles: OSI_TILE_AUTO, OSI_TILE_64x64_S1, OSI_TILE_64x128_S1. */
 int osi_conv_fwd_act(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
                      int tile, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
+/* 1x1 stride-1 convolution whose input is a whole bottleneck OUTPUT recomputed in the loader: A = relu(x * in_scale[c] + in_shift[c]
+ * + res) with x = conv3's pre-BN output and res = the identity shortcut (same shape). conv1 of the next bottleneck can start
+ * without waiting for the block-output pass (which still materialises the tensor for the later consumers, on another stream).
+ * The value is bit-identical to what osi_bn_apply_relu_mask writes (one fma, one add, max). */
+int osi_conv_fwd_act2(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* res,
+                      const float* w, float* y, int tile, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block,
+                      osi_stream_t stream);
 /* dx (+)= conv2d_input_grad(dy, w). accumulate != 0 adds into dx (skip-connection sum). Cout % 32 == 0, Cin % 64 == 0. */
 int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, int tile,
                    osi_stream_t stream);
@@ -265,7 +272,8 @@ int osi_resnet50_backward(osi_resnet50_t net, const float* params, float* grads,
  * `stream` at the end of every backward stage). enable = 0 serialises everything on the caller's stream. */
 int osi_resnet50_set_overlap(osi_resnet50_t net, int enable);
 /* Per-executor switches: "overlap" (= osi_resnet50_set_overlap), "fwd_fork" (projection shortcut of the forward pass on the side
- * stream, default 1), "side_priority_normal" (side stream at default instead of lowest priority; only before the first training
+ * stream, default 1), "fwd_recompute" (conv1 of a bottleneck recomputes the previous identity-shortcut block output in its loader and
+ * that block's output pass runs beside it on the side stream, default 1), "side_priority_normal" (side stream at default instead of lowest priority; only before the first training
  * call, else OSI_ERR_STATE). Unknown name -> OSI_ERR_ARG. */
 int osi_resnet50_set_option(osi_resnet50_t net, const char* name, int value);
 

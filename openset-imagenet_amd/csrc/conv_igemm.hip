@@ -65,6 +65,7 @@ struct ConvP {
     // the end stay exact zeros (the select runs AFTER the activation).
     const float* in_scale;
     const float* in_shift;
+    const float* res;     // fwd XF = 2: shortcut tensor added before the ReLU (same shape as x)
     size_t slab_stride;
 };
 
@@ -163,10 +164,12 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // ======================================================================================================
 // NST = LDS stages: 2 = double buffered (one barrier per K tile), 1 = single buffered (two barriers, half the LDS, twice the
 // resident workgroups per CU)
-// XF: the A operand is relu(x * in_scale[c] + in_shift[c]) (fused BatchNorm-apply + ReLU of the producer layer)
+// XF = 1: the A operand is relu(x * in_scale[c] + in_shift[c]) (fused BatchNorm-apply + ReLU of the producer layer)
+// XF = 2 (1x1 stride-1 only): the A operand is relu(x * in_scale[c] + in_shift[c] + res) — a whole block output (bn3 + identity
+//         shortcut + ReLU) recomputed in the loader, so conv1 of the NEXT bottleneck need not wait for the block-output pass
 // (the fused forms pin the register budget of their plain twins — 8 / 5 waves per SIMD — so that the extra loader work cannot
 // cost occupancy, which is what these kernels live on)
-template <int WM, int WN, bool STEM, int NST, bool XF = false>
+template <int WM, int WN, bool STEM, int NST, int XF = 0>
 __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2)) void k_conv_fwd(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32, BR = BN / 32;  // float4 loads per thread per stage
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     unsigned a_taps[AR];
     bool a_ok[AR];
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.w, p.w_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(XF == 2 ? p.res : p.x, p.x_bytes);   // XF = 2: the shortcut tensor, same shape as x
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int m = m0 + lr + 32 * i;
@@ -235,9 +239,14 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     int r = 0, s = 0, c0 = 0;  // current tap / channel offset (non-stem)
     int ld_c0 = 0, ld_tap = 0; // XF: channel offset / tap index of the tile sitting in ra (set by gload, used by sstore)
     f32x4 ra[AR], rb[BR];
+    f32x4 rr[XF == 2 ? AR : 1];   // XF = 2: the shortcut rows of the tile sitting in ra
 
     auto gload = [&](int t) {
         if (XF) { ld_c0 = p.unit ? t * BK : c0; ld_tap = r * p.S + s; }
+        if (XF == 2) {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) rr[i] = bld4(rres, (uint32_t)a_base[i], (uint32_t)(t * BK * 4));
+        }
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             if (STEM) {
@@ -271,7 +280,11 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
         for (int i = 0; i < AR; ++i) {
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(ra[i][e], sc[e], sh[e]), 0.f);
+            for (int e = 0; e < 4; ++e) {
+                float t = __builtin_fmaf(ra[i][e], sc[e], sh[e]);
+                if (XF == 2) t += rr[i][e];      // same two roundings as k_bn_apply<RES = 1>: fma, then add
+                v[e] = fmaxf(t, 0.f);
+            }
             // 1x1 stride-1: only rows past M are invalid and their results are never stored; otherwise padding taps must read as
             // the zero the reference pads the ACTIVATION with
             const bool ok = p.unit ? true : (((a_taps[i] >> ld_tap) & 1) != 0);
@@ -965,7 +978,7 @@ static ConvP make_p(const osi_conv_desc* d) {
     return p;
 }
 
-template <int WM, int WN, bool STEM, int NST = 2, bool XF = false>
+template <int WM, int WN, bool STEM, int NST = 2, int XF = 0>
 static int launch_fwd(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     p.MT = osi_cdiv(p.M, BM); p.NT = p.Cout / BN;
@@ -1088,7 +1101,7 @@ static int fwd_tile_rows(int tile) {
 }
 static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, float* pstats,
                          size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream, const float* in_scale = nullptr,
-                         const float* in_shift = nullptr);
+                         const float* in_shift = nullptr, const float* res = nullptr);
 
 int osi_conv_fwd(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, osi_stream_t stream) {
     return conv_fwd_impl(d, x, w, y, tile, nullptr, 0, nullptr, nullptr, stream);
@@ -1099,6 +1112,15 @@ int osi_conv_fwd_act(const osi_conv_desc* d, const float* x, const float* in_sca
     OSI_REQUIRE(in_scale && in_shift);
     OSI_REQUIRE(!pstats || (P && rows_per_block));
     return conv_fwd_impl(d, x, w, y, tile, pstats, pstats_bytes, P, rows_per_block, stream, in_scale, in_shift);
+}
+
+int osi_conv_fwd_act2(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* res,
+                      const float* w, float* y, int tile, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block,
+                      osi_stream_t stream) {
+    OSI_REQUIRE(in_scale && in_shift && res);
+    OSI_REQUIRE(!pstats || (P && rows_per_block));
+    OSI_REQUIRE(d && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0);   // the input is a block output: conv1 of a bottleneck
+    return conv_fwd_impl(d, x, w, y, tile, pstats, pstats_bytes, P, rows_per_block, stream, in_scale, in_shift, res);
 }
 
 size_t osi_conv_fwd_bnstats_workspace(const osi_conv_desc* d) {
@@ -1115,12 +1137,12 @@ int osi_conv_fwd_bnstats(const osi_conv_desc* d, const float* x, const float* w,
 
 static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, float* pstats,
                          size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream, const float* in_scale,
-                         const float* in_shift) {
+                         const float* in_shift, const float* res) {
     OSI_REQUIRE(desc_ok(d) && x && w && y);
     hipStream_t st = (hipStream_t)stream;
     ConvP p = make_p(d);
     p.x = x; p.w = w; p.y = y; p.accumulate = 0;
-    p.in_scale = in_scale; p.in_shift = in_shift;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.res = res;
     OSI_REQUIRE(!in_scale || (!is_stem(d) && d->Cin <= 4096 && d->R * d->S <= 32));
     p.unit = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) ? 1 : 0;
     p.x_bytes = (int)((size_t)d->B * d->H * d->W * d->Cin * 4);
@@ -1151,8 +1173,11 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
     }
     if (int e = with_stats(fwd_tile_rows(tile))) return e;
     if (in_scale) {   // fused input activation: built for the single-buffered 64-row tiles the executor uses
-        if (tile == OSI_TILE_64x64_S1) return launch_fwd<1, 1, false, 1, true>(p, st);
-        if (tile == OSI_TILE_64x128_S1) { OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<1, 2, false, 1, true>(p, st); }
+        if (tile == OSI_TILE_64x64_S1) return res ? launch_fwd<1, 1, false, 1, 2>(p, st) : launch_fwd<1, 1, false, 1, 1>(p, st);
+        if (tile == OSI_TILE_64x128_S1) {
+            OSI_REQUIRE(d->Cout % 128 == 0);
+            return res ? launch_fwd<1, 2, false, 1, 2>(p, st) : launch_fwd<1, 2, false, 1, 1>(p, st);
+        }
         return OSI_ERR_ARG;
     }
     switch (tile) {

@@ -144,6 +144,7 @@ struct osi_resnet50 {
     void* staged_ws = nullptr;   // workspace whose input buffer was filled by osi_resnet50_stage_input_u8 (consumed by one forward)
     bool overlap = true;
     bool fwd_fork = true;            // projection shortcut of the forward pass on the side stream
+    bool fwd_recompute = true;       // identity-shortcut block outputs recomputed by the next conv1, their pass moved off the critical path
     bool side_prio_normal = false;   // side stream at default instead of lowest priority (read when the stream is created)
     const float* x4_ext = nullptr;   // external NHWC4 input bound by osi_resnet50_bind_input_nhwc4 (consumed by one forward)
     const float* x4_cur = nullptr;   // input of the step in flight (forward sets it, the stem weight gradient reads it)
@@ -354,8 +355,10 @@ int osi_resnet50_profile_read(osi_resnet50_t n, double* ms, int* count) {
 
 // conv ci + its BatchNorm statistics. in_bn >= 0: the conv's input is the PRE-BN output of the layer whose BatchNorm is `in_bn`;
 // that BatchNorm + ReLU is applied inside the conv's operand loader (osi_conv_fwd_act) — the activation never exists in HBM.
+// in_res != NULL (with in_bn): x is conv3's pre-BN output of the previous bottleneck and in_res its identity shortcut — the whole block
+// output relu(bn3(x) + in_res) is recomputed in the loader (osi_conv_fwd_act2).
 static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buffers, float* ws, const float* x, const float* w,
-                       int training, hipStream_t st, size_t bn_ws_off, int in_bn = -1) {
+                       int training, hipStream_t st, size_t bn_ws_off, int in_bn = -1, const float* in_res = nullptr) {
     Conv& c = n->convs[ci];
     BN& b = n->bns[c.bn];
     const float* isc = in_bn >= 0 ? ws + n->bns[in_bn].scale : nullptr;
@@ -363,14 +366,16 @@ static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buff
     if (training) {
         // batch statistics come out of the conv epilogue (per row tile), only a tiny per-channel merge follows
         int P = 0, rows = 0;
-        if (isc) OSI_TRY(osi_conv_fwd_act(&c.d, x, isc, ish, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
+        if (isc && in_res) OSI_TRY(osi_conv_fwd_act2(&c.d, x, isc, ish, in_res, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
+        else if (isc) OSI_TRY(osi_conv_fwd_act(&c.d, x, isc, ish, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
         else OSI_TRY(osi_conv_fwd_bnstats(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
         OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
         OSI_TRY(osi_bn_finalize_stats(ws + bn_ws_off, n->bn_ws_bytes, P, rows, b.M, b.C, params + b.g_off, params + b.b_off, 1e-5f, 0.1f,
                                       buffers + b.rm_off, buffers + b.rv_off, ws + b.mean, ws + b.invstd, ws + b.scale,
                                       ws + b.shift, st));
     } else {
-        if (isc) OSI_TRY(osi_conv_fwd_act(&c.d, x, isc, ish, w, ws + c.y, OSI_TILE_AUTO, nullptr, 0, nullptr, nullptr, st));
+        if (isc && in_res) OSI_TRY(osi_conv_fwd_act2(&c.d, x, isc, ish, in_res, w, ws + c.y, OSI_TILE_AUTO, nullptr, 0, nullptr, nullptr, st));
+        else if (isc) OSI_TRY(osi_conv_fwd_act(&c.d, x, isc, ish, w, ws + c.y, OSI_TILE_AUTO, nullptr, 0, nullptr, nullptr, st));
         else OSI_TRY(osi_conv_fwd(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, st));
         OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
         OSI_TRY(osi_bn_eval_coeffs(buffers + b.rm_off, buffers + b.rv_off, params + b.g_off, params + b.b_off, 1e-5f, b.C,
@@ -423,29 +428,50 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
     // bottleneck blocks. Only the block outputs (residual sums) are materialised: conv2 / conv3 read the pre-BN output of the conv
     // before them and apply its BatchNorm + ReLU in their operand loader; the projection shortcut's BatchNorm is applied inside the
-    // block-output kernel. Per block: 3 (4) convs + one apply pass instead of 3 (4) convs + 3 (4) apply passes.
-    for (Block& k : n->blocks) {
+    // block-output kernel. Per block: 3 (4) convs + one block-output pass instead of 3 (4) convs + 3 (4) apply passes.
+    // The block-output pass itself is HBM-bound and sits between two matrix-bound convolutions. For a block with an identity shortcut
+    // it is taken OFF the critical path: conv1 of the next block recomputes relu(bn3(y3) + x) in its loader (osi_conv_fwd_act2) and
+    // the pass that materialises the tensor (for the next shortcut, the projection conv and the backward) runs beside it on the side stream.
+    const int nb = (int)n->blocks.size();
+    bool deferred = false;          // the previous block's output pass has not been enqueued yet
+    for (int bi = 0; bi < nb; ++bi) {
+        Block& k = n->blocks[bi];
         const float* x = ws + k.x_in;
-        // The projection shortcut (4 blocks) only depends on the block input: with overlap on it runs on the side stream beside
-        // the main branch (its own BatchNorm scratch), and is joined before the residual add.
+        const bool async = n->async_wgrad();
+        hipStream_t sd = async ? n->side : st;      // stream of the work that runs beside the main branch
         bool forked = false;
-        if (k.ds >= 0) {
-            Conv& c = n->convs[k.ds];
-            hipStream_t ds_st = st;
-            if (n->fwd_fork && n->async_wgrad()) {
-                if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
-                if (hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) return OSI_ERR_LAUNCH;
-                ds_st = n->side; forked = true;
-            }
-            OSI_TRY(conv_bn_fwd(n, k.ds, params, buffers, ws, x, params + c.w_off, training, ds_st, forked ? n->bn_ws2 : n->bn_ws));
-            if (forked && hipEventRecord(n->ev_join, n->side) != hipSuccess) return OSI_ERR_LAUNCH;
+        if ((deferred || (k.ds >= 0 && n->fwd_fork)) && async) {
+            if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
+            if (hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+            forked = true;
         }
+        const Block* pk = bi > 0 ? &n->blocks[bi - 1] : nullptr;
+        if (deferred) {             // materialise the previous block's output (this block's shortcut / projection input)
+            Conv& c3p = n->convs[pk->c3];
+            BN& b3p = n->bns[c3p.bn];
+            OSI_TRY(osi_bn_apply_relu_mask(ws + c3p.y, ws + pk->x_in, ws + b3p.scale, ws + b3p.shift, ws + c3p.a, ws + c3p.mask, b3p.M,
+                                           b3p.C, sd));
+            OSI_TRY(n->mark(OSI_PROF_BN_FWD, sd));
+        }
+        if (k.ds >= 0) {            // the projection shortcut only depends on the block input: beside the main branch (own BN scratch)
+            Conv& c = n->convs[k.ds];
+            hipStream_t ds_st = (n->fwd_fork || deferred) ? sd : st;   // behind a deferred pass it must follow it on that stream
+            OSI_TRY(conv_bn_fwd(n, k.ds, params, buffers, ws, x, params + c.w_off, training, ds_st, ds_st != st ? n->bn_ws2 : n->bn_ws));
+        }
+        if (forked && hipEventRecord(n->ev_join, n->side) != hipSuccess) return OSI_ERR_LAUNCH;
         Conv &c1 = n->convs[k.c1], &c2 = n->convs[k.c2], &c3 = n->convs[k.c3];
-        OSI_TRY(conv_bn_fwd(n, k.c1, params, buffers, ws, x, params + c1.w_off, training, st, n->bn_ws));
+        if (deferred) {
+            Conv& c3p = n->convs[pk->c3];
+            OSI_TRY(conv_bn_fwd(n, k.c1, params, buffers, ws, ws + c3p.y, params + c1.w_off, training, st, n->bn_ws, c3p.bn, ws + pk->x_in));
+        } else {
+            OSI_TRY(conv_bn_fwd(n, k.c1, params, buffers, ws, x, params + c1.w_off, training, st, n->bn_ws));
+        }
         OSI_TRY(conv_bn_fwd(n, k.c2, params, buffers, ws, ws + c1.y, params + c2.w_off, training, st, n->bn_ws, c1.bn));
         OSI_TRY(conv_bn_fwd(n, k.c3, params, buffers, ws, ws + c2.y, params + c3.w_off, training, st, n->bn_ws, c2.bn));
         if (forked && hipStreamWaitEvent(st, n->ev_join, 0) != hipSuccess) return OSI_ERR_LAUNCH;
         BN& b3 = n->bns[c3.bn];
+        deferred = n->fwd_recompute && k.ds < 0 && bi + 1 < nb;
+        if (deferred) continue;     // the next iteration enqueues this block's output pass beside its conv1
         if (k.ds >= 0) {
             Conv& cd = n->convs[k.ds];
             BN& bd = n->bns[cd.bn];
@@ -719,6 +745,7 @@ int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
     OSI_REQUIRE(n && name);
     if (!strcmp(name, "overlap")) n->overlap = value != 0;
     else if (!strcmp(name, "fwd_fork")) n->fwd_fork = value != 0;
+    else if (!strcmp(name, "fwd_recompute")) n->fwd_recompute = value != 0;
     else if (!strcmp(name, "side_priority_normal")) {
         if (n->side) return OSI_ERR_STATE;   // the side stream already exists with the other priority
         n->side_prio_normal = value != 0;

@@ -40,6 +40,7 @@ _SIGS = {
     "osi_get_tuning": (c_int, [c_char_p, POINTER(c_int)]),
     "osi_conv_fwd": (c_int, [_PD, P, P, P, c_int, P]),
     "osi_conv_fwd_act": (c_int, [_PD, P, P, P, P, P, c_int, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
+    "osi_conv_fwd_act2": (c_int, [_PD, P, P, P, P, P, P, c_int, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
     "osi_conv_wgrad_act": (c_int, [_PD, P, P, P, P, P, P, c_size_t, P]),
     "osi_conv_fwd_bnstats_workspace": (c_size_t, [_PD]),
     "osi_conv_fwd_bnstats": (c_int, [_PD, P, P, P, c_int, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),

@@ -151,3 +151,42 @@ def test_block_output_with_fused_shortcut_batchnorm(cuda, M, C):
     assert torch.equal(out1, out2) and torch.equal(m1, m2)
     ref = torch.relu(y.double() * sc.double() + sh.double() + ry.double() * rsc.double() + rsh.double())
     assert float((out2.double() - ref).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,H,B,tile", [(256, 64, 14, 3, 0), (512, 128, 9, 2, 5), (1024, 256, 7, 5, 6), (2048, 512, 7, 3, 0)])
+def test_conv1_recomputes_the_previous_block_output(cuda, Cin, Cout, H, B, tile):
+    """osi_conv_fwd_act2: the A operand relu(x * scale + shift + res) — a whole identity-shortcut block output — recomputed in the
+    loader gives exactly the bits of the plain convolution on the tensor osi_bn_apply_relu_mask materialises (same fma, add, max; same
+    tile and K order), and its BatchNorm partials are those of the plain fused form."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(Cin + H)
+    M = B * H * H
+    y3 = (torch.randn(B, H, H, Cin, generator=g) * 1.3).to(cuda)
+    res = torch.relu(torch.randn(B, H, H, Cin, generator=g)).to(cuda)
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).to(cuda), (torch.randn(Cin, generator=g) * 0.5).to(cuda)
+    w = (torch.randn(Cout, 1, 1, Cin, generator=g) / Cin ** 0.5).to(cuda)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, 1, 1, 0)
+    out = torch.empty(M, Cin, device=cuda)
+    mask = torch.zeros(L.osi_bn_relu_mask_bytes(M, Cin), dtype=torch.uint8, device=cuda)
+    N.check(L.osi_bn_apply_relu_mask(N.ptr(y3), N.ptr(res), N.ptr(sc), N.ptr(sh), N.ptr(out), N.ptr(mask), M, Cin, T.S()))
+    pb = L.osi_conv_fwd_bnstats_workspace(ctypes.byref(d))
+    ys, ps, Ps = [], [], []
+    for fused in (False, True):
+        y = torch.full((B, H, H, Cout), float("nan"), device=cuda)
+        p = torch.full((pb // 4,), float("nan"), device=cuda)
+        P, rows = ctypes.c_int(), ctypes.c_int()
+        if fused:
+            N.check(L.osi_conv_fwd_act2(ctypes.byref(d), N.ptr(y3), N.ptr(sc), N.ptr(sh), N.ptr(res), N.ptr(w), N.ptr(y), tile, N.ptr(p), pb,
+                                        ctypes.byref(P), ctypes.byref(rows), T.S()), "osi_conv_fwd_act2")
+        else:
+            N.check(L.osi_conv_fwd_bnstats(ctypes.byref(d), N.ptr(out), N.ptr(w), N.ptr(y), tile if tile else 0, N.ptr(p), pb, ctypes.byref(P),
+                                           ctypes.byref(rows), T.S()))
+        ys.append(y); ps.append(p[:2 * P.value * Cout].clone()); Ps.append((P.value, rows.value))
+    assert Ps[0] == Ps[1] and torch.equal(ys[0], ys[1]) and torch.equal(ps[0], ps[1])
+    ref = F.conv2d(T.nchw(torch.relu(y3.double() * sc.double() + sh.double() + res.double())), T.oihw(w.double())).permute(0, 2, 3, 1)
+    assert float((ys[1].double() - ref).abs().max()) <= (2e-6 + 6e-8 * Cin ** 0.5) * float(ref.abs().max()) + 1e-6
+    # 3x3 / strided descriptors are refused: the input must be a block output feeding a 1x1 stride-1 conv
+    d3 = N.ConvDesc.make(B, H, H, Cin, Cout, 3, 1, 1)
+    assert L.osi_conv_fwd_act2(ctypes.byref(d3), N.ptr(y3), N.ptr(sc), N.ptr(sh), N.ptr(res), N.ptr(w), N.ptr(ys[0]), 0, None, 0, None, None, T.S()) == -1
