@@ -273,7 +273,7 @@ int osi_resnet50_backward(osi_resnet50_t net, const float* params, float* grads,
 int osi_resnet50_set_overlap(osi_resnet50_t net, int enable);
 /* Per-executor switches: "overlap" (= osi_resnet50_set_overlap), "fwd_fork" (projection shortcut of the forward pass on the side
  * stream, default 1), "fwd_recompute" (conv1 of a bottleneck recomputes the previous identity-shortcut block output in its loader and
- * that block's output pass runs beside it on the side stream, default 1), "side_priority_normal" (side stream at default instead of lowest priority; only before the first training
+ * that block's output pass runs beside it on the side stream; default 0: measured no faster), "side_priority_normal" (side stream at default instead of lowest priority; only before the first training
  * call, else OSI_ERR_STATE). Unknown name -> OSI_ERR_ARG. */
 int osi_resnet50_set_option(osi_resnet50_t net, const char* name, int value);
 

@@ -144,7 +144,9 @@ struct osi_resnet50 {
     void* staged_ws = nullptr;   // workspace whose input buffer was filled by osi_resnet50_stage_input_u8 (consumed by one forward)
     bool overlap = true;
     bool fwd_fork = true;            // projection shortcut of the forward pass on the side stream
-    bool fwd_recompute = true;       // identity-shortcut block outputs recomputed by the next conv1, their pass moved off the critical path
+    bool fwd_recompute = false;      // identity-shortcut block outputs recomputed by the next conv1, their pass moved off the critical
+                                     // path. Built, bit-exact, and measured: NO gain (35.48 vs 35.45 ms) — conv1 with the second operand
+                                     // stream is 5-27 % slower, which eats the hidden pass. Off by default; kept for A/B.
     bool side_prio_normal = false;   // side stream at default instead of lowest priority (read when the stream is created)
     const float* x4_ext = nullptr;   // external NHWC4 input bound by osi_resnet50_bind_input_nhwc4 (consumed by one forward)
     const float* x4_cur = nullptr;   // input of the step in flight (forward sets it, the stem weight gradient reads it)
@@ -429,9 +431,10 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     // bottleneck blocks. Only the block outputs (residual sums) are materialised: conv2 / conv3 read the pre-BN output of the conv
     // before them and apply its BatchNorm + ReLU in their operand loader; the projection shortcut's BatchNorm is applied inside the
     // block-output kernel. Per block: 3 (4) convs + one block-output pass instead of 3 (4) convs + 3 (4) apply passes.
-    // The block-output pass itself is HBM-bound and sits between two matrix-bound convolutions. For a block with an identity shortcut
-    // it is taken OFF the critical path: conv1 of the next block recomputes relu(bn3(y3) + x) in its loader (osi_conv_fwd_act2) and
-    // the pass that materialises the tensor (for the next shortcut, the projection conv and the backward) runs beside it on the side stream.
+    // The block-output pass itself is HBM-bound and sits between two matrix-bound convolutions. Option "fwd_recompute" takes it off the
+    // critical path for blocks with an identity shortcut: conv1 of the next block recomputes relu(bn3(y3) + x) in its loader
+    // (osi_conv_fwd_act2) and the pass that materialises the tensor (for the next shortcut, the projection conv and the backward) runs
+    // beside it on the side stream. Default off (no measured gain, see the member's comment).
     const int nb = (int)n->blocks.size();
     bool deferred = false;          // the previous block's output pass has not been enqueued yet
     for (int bi = 0; bi < nb; ++bi) {

@@ -42,8 +42,8 @@ class _Net:
         # development A/B switches (environment read here, handed to the executor explicitly)
         if os.environ.get("OSI_NO_OVERLAP"):     # keep the weight-gradient kernels on the main stream
             N.check(N.lib().osi_resnet50_set_option(self.h, b"overlap", 0))
-        if os.environ.get("OSI_FWD_RECOMPUTE") == "0":
-            N.check(N.lib().osi_resnet50_set_option(self.h, b"fwd_recompute", 0))
+        if os.environ.get("OSI_FWD_RECOMPUTE") == "1":
+            N.check(N.lib().osi_resnet50_set_option(self.h, b"fwd_recompute", 1))
         if os.environ.get("OSI_FWD_FORK") == "0":
             N.check(N.lib().osi_resnet50_set_option(self.h, b"fwd_fork", 0))
         if os.environ.get("OSI_SIDE_PRIO", "")[:1] == "n":

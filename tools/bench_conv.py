@@ -30,7 +30,7 @@ def timeit(fn):
 
 
 tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
-print(f"B={B}  TFLOP/s per tile: auto,128x128,64x128,64x64,64x64_S1,64x128_S1,128x128_S1,128x64_S1[,auto with fused input activation]; wgrad: plain, fused")
+print(f"B={B}  TFLOP/s per tile: auto,128x128,64x128,64x64,64x64_S1,64x128_S1,128x128_S1,128x64_S1[,auto with fused input activation[,auto recomputing a block output (1x1 s1)]]; wgrad: plain, fused")
 for Cin, Cout, k, s, H, cnt in SHAPES:
     pad = 1 if k == 3 else 0
     d = N.ConvDesc.make(B, H, H, Cin, Cout, k, s, pad)
@@ -61,6 +61,10 @@ for Cin, Cout, k, s, H, cnt in SHAPES:
     sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.5
     f = lambda: N.check(L.osi_conv_fwd_act(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(w), N.ptr(y), 0, None, 0, None, None, S()))
     res["fwd"].append(flop / timeit(f) / 1e9)
+    if k == 1 and s == 1:   # conv1 recomputing the previous block output: relu(x * sc + sh + res)
+        res_t = torch.rand_like(x)
+        f = lambda: N.check(L.osi_conv_fwd_act2(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(res_t), N.ptr(w), N.ptr(y), 0, None, 0, None, None, S()))
+        res["fwd"].append(flop / timeit(f) / 1e9)
     f = lambda: N.check(L.osi_conv_wgrad_act(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(dw), N.ptr(ws), nb, S()))
     res["wgrad"].append(flop / timeit(f) / 1e9)
     for n in res:
