@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*wgrad_group*/ 2};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 32, /*wgrad_group*/ 2};
 
 namespace {
 int* tuning_slot(const char* name) {
@@ -12,6 +12,7 @@ int* tuning_slot(const char* name) {
     if (!strcmp(name, "wgrad_blocks")) return &g_osi_tuning.wgrad_blocks;
     if (!strcmp(name, "wgrad_nst")) return &g_osi_tuning.wgrad_nst;
     if (!strcmp(name, "bn_grid")) return &g_osi_tuning.bn_grid;
+    if (!strcmp(name, "bn_single_p")) return &g_osi_tuning.bn_single_p;
     if (!strcmp(name, "wgrad_group")) return &g_osi_tuning.wgrad_group;
     return nullptr;
 }
@@ -25,6 +26,7 @@ int osi_set_tuning(const char* name, int value) {
     if (s == &g_osi_tuning.wgrad_blocks && value < 1) return OSI_ERR_ARG;
     if (s == &g_osi_tuning.wgrad_nst && value != 1 && value != 2) return OSI_ERR_ARG;
     if (s == &g_osi_tuning.bn_grid && value < 1) return OSI_ERR_ARG;
+    if (s == &g_osi_tuning.bn_single_p && value < 1) return OSI_ERR_ARG;
     *s = value;
     return OSI_OK;
 }

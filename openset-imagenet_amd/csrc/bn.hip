@@ -480,7 +480,7 @@ int osi_bn_finalize_stats(float* pstats, size_t pstats_bytes, int P, int rows_pe
     hipStream_t st = (hipStream_t)stream;
     const float* pmean = pstats;
     const float* pm2 = pstats + (size_t)P * C;
-    if (P <= 32) {
+    if (P <= g_osi_tuning.bn_single_p) {   // one launch merges up to this many row-tile partials per channel (measured knob)
         hipLaunchKernelGGL(k_bn_stats_final_rows, dim3(osi_cdiv(C, 16)), dim3(NT), 0, st, pmean, pm2, P, rows_per_block, M, C, gamma,
                            beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
         OSI_LAUNCH_CHECK();

@@ -26,6 +26,7 @@ struct OsiTuning {
     int wgrad_blocks;   // split-K footprint budget of one weight-gradient launch, in 64x64-workgroup units
     int wgrad_nst;      // LDS stages of the weight-gradient kernel (1 or 2)
     int bn_grid;        // grid cap of the BatchNorm stream kernels
+    int bn_single_p;    // BatchNorm statistics: row-tile partials merged by ONE launch up to this count, two-level above it
     int wgrad_group;    // weight-gradient block -> XCD mapping: 0 plain 2-D grid, 1 the R*S taps of a cell share an XCD, 2 whole K splits do
 };
 extern OsiTuning g_osi_tuning;

@@ -198,8 +198,10 @@ class DevicePrefetcher:
                 t.record_stream(cur)                  # allocator: these blocks were allocated on the copy stream
             k += 1
             nxt = self._load(it, k)                   # batch k+1 is copied and staged while the caller trains on batch k
-            yield images, labels
-            done = torch.cuda.Event()                 # the caller has enqueued everything that reads this slot
-            done.record(torch.cuda.current_stream(self.device))
-            self._free[slot] = done
+            try:
+                yield images, labels
+            finally:                                  # also when the caller leaves the loop early (generator closed)
+                done = torch.cuda.Event()             # the caller has enqueued everything that reads this slot
+                done.record(torch.cuda.current_stream(self.device))
+                self._free[slot] = done
             del host
