@@ -851,8 +851,10 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 3 : (WM * WN == 2 ?
 #pragma unroll
         for (int i = 0; i < BRN; ++i) {
             const int row = b_row + BRP * i;
-            // a zero operand row (pixel past the split's end, or a padding tap) must stay zero: select after the activation
-            const bool ok = p.unit ? (kbeg + ld_t * BK + row < kend) : (tbl[(ld_t % TW) * BK + row] != OOB);
+            // A padding tap must read as zero AFTER the activation: select. Pixels past the split's end need nothing: their dY row
+            // is zero (range-checked load), so whatever finite value relu(shift) leaves in the X row is multiplied away — the 1x1
+            // stride-1 form has no padding and therefore no select at all.
+            const bool ok = p.unit ? true : (tbl[(ld_t % TW) * BK + row] != OOB);
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(rbv[i][e], sc[e], sh[e]), 0.f);
