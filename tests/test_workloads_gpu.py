@@ -178,3 +178,35 @@ def test_hip_model_vs_transformers_witness(cuda, golden_dir):
                 for key in W.files:
                     if key.startswith(p + "resnet_base.") and key.endswith(("running_mean", "running_var")):
                         assert np.allclose(st[key[len(p):]].cpu().double().numpy(), W[key], rtol=1e-4, atol=1e-5), key
+
+
+def test_protocol1_softmax_config_vs_oracle(cuda):
+    """BASELINE.json configs[0] (Protocol 1, softmax cross-entropy, the reference's CPU-runnable case) on the GPU path: C = 116,
+    `CrossEntropyLoss(ignore_index=-1)` on a training batch without negatives (train.py:291-293, 343) and on a validation batch WITH
+    negatives (ignored), forward + backward against the fp64 oracle at a size the CPU affords."""
+    from openset_imagenet import ResNet50, SoftmaxLoss
+    from oracle import resnet50_oracle as R, losses_oracle as L
+    C, B, HW = 116, 8, 96
+    gen = torch.Generator().manual_seed(44)
+    sd = R.init_state(C, C, False, generator=gen)
+    model = ResNet50(C, C, False)
+    model.load_state_dict(sd)
+    model = model.to(cuda)
+    x = torch.rand(B, 3, HW, HW, generator=gen)
+    for y in (torch.randint(0, C, (B,), generator=gen), torch.tensor([3, -1, 115, -1, 0, 57, -1, 9])):
+        model.load_state_dict(sd)
+        model.train()
+        logits, _ = model(x.to(cuda))
+        j = SoftmaxLoss(ignore_index=-1)(logits, y.to(cuda))
+        j.backward()
+        ref_fn = lambda lg, t, f: L.softmax_loss(lg, t)
+        r32 = R.forward_backward({k: v.clone() for k, v in sd.items()}, x, y, ref_fn)
+        r64 = R.forward_backward({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}, x.double(), y, ref_fn)
+        assert float((logits.detach().cpu().double() - r64[0]).abs().max()) <= LOGIT_TOL
+        assert abs(float(j) - float(r64[2])) <= 1e-5 * max(1.0, abs(float(r64[2])))
+        named = dict(model.named_parameters())
+        mine = [_rel(named[k].grad.cpu(), r64[3][k]) for k in R.param_keys(sd)]
+        ref = [_rel(r32[3][k], r64[3][k]) for k in R.param_keys(sd)]
+        assert np.median(mine) <= 2 * np.median(ref) + 1e-5 and max(mine) <= 5 * max(ref) + 2e-4
+        # rows with the ignored label contribute no gradient: the head gradient matches the oracle tightly
+        assert _rel(named["logits.weight"].grad.cpu(), r64[3]["logits.weight"]) <= 5 * _rel(r32[3]["logits.weight"], r64[3]["logits.weight"]) + 1e-5
