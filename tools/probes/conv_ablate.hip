@@ -139,6 +139,84 @@ __global__ __launch_bounds__(256, V == 6 ? 6 : 8) void k_gemm(const float* __res
     }
 }
 
+// V10: the full loop with LDS-DMA staging (global_load_lds_dwordx4: global -> LDS without a VGPR round trip, no ds_write), two LDS
+// buffers, ONE barrier per K tile. The LDS image is unpadded [rows][32 floats]; bank conflicts of the ds_read_b128 fragment reads are
+// avoided by XOR-swizzling the 16-byte slot with (row >> 1) & 7 — on the SOURCE address of the DMA and on the read, never on the
+// DMA's destination (which is wave-uniform base + lane * 16).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+__global__ __launch_bounds__(256, 5) void k_gemm_dma(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int M,
+                                                    int N, int K, int MT, int NT) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int nt = slot % NT, mt = (slot / NT) * 8 + xcd;
+    if (mt >= MT) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = mt * 64, n0 = nt * 64;
+    constexpr int TILE = 64 * 32;             // floats per operand tile
+    constexpr int STG = 2 * TILE;             // A | B
+    // this lane's two rows per operand (pass i: rows 32 i + 8 wave + lane / 8), physical slot lane & 7 -> logical (source) slot
+    size_t a_src[2], b_src[2];
+    for (int i = 0; i < 2; ++i) {
+        const int r = 32 * i + 8 * wave + (lane >> 3);
+        const int sl = (lane & 7) ^ ((r >> 1) & 7);
+        int m = m0 + r; if (m >= M) m = M - 1;          // rows past the end: any valid address, their results are never stored
+        a_src[i] = (size_t)m * K + sl * 4;
+        b_src[i] = (size_t)(n0 + r) * K + sl * 4;
+    }
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int T = K / BK;
+    auto dma = [&](int t, int buf) {
+        float* sA = smem + buf * STG; float* sB = sA + TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(X + a_src[i] + (size_t)t * BK), (lds_ptr_t)(sA + (32 * i + 8 * wave) * 32), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(W + b_src[i] + (size_t)t * BK), (lds_ptr_t)(sB + (32 * i + 8 * wave) * 32), 16, 0, 0);
+        }
+    };
+    const int h = lane >> 5, l31 = lane & 31;
+    const int ra_ = wm * 32 + l31, rb_ = wn * 32 + l31;
+    const int fa = (ra_ >> 1) & 7, fb = (rb_ >> 1) & 7;
+    dma(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) dma(t + 1, buf ^ 1);
+        const float* sA = smem + buf * STG; const float* sB = sA + TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sA + ra_ * 32 + (((2 * j + h) ^ fa) << 2));
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sB + rb_ * 32 + (((2 * j + h) ^ fb) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        }
+        __syncthreads();      // hipcc drains vmcnt(0) here: tile t+1 has landed, and every wave is done reading tile t
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    for (int r = 0; r < 16; ++r) {
+        int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M) Y[(size_t)m * N + col] = acc[r];
+    }
+}
+static float run10(const float* X, const float* W, float* Y, int M, int N, int K, int reps) {
+    const int MT = (M + 63) / 64, NT = N / 64;
+    const int grid = (MT + 7) / 8 * 8 * NT;
+    const size_t smem = (size_t)2 * 2 * 64 * 32 * sizeof(float);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_gemm_dma, dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_gemm_dma, dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
 // V9: the full loop on a 32 (M) x 64 (N) tile with TWO waves (128 threads): twice the workgroups of the 64x64 form for the layers
 // that have only 3-6 of those per CU (14x14 and 7x7 spatial sizes), at 1.5x the operand traffic per FLOP.
 __global__ __launch_bounds__(128, 8) void k_gemm_32x64(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int M,
@@ -235,15 +313,23 @@ int main() {
         hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice);
         hipMemcpy(W, h.data(), (size_t)s.N * s.K * 4, hipMemcpyHostToDevice);
         const double gflop = 2.0 * s.M * s.N * s.K / 1e9;
+        {   // V10 must compute the same GEMM as V0 (same K order inside a tile: bitwise)
+            std::vector<float> y0((size_t)s.M * s.N), y1((size_t)s.M * s.N);
+            run<0>(X, W, Y, s.M, s.N, s.K, 1); hipMemcpy(y0.data(), Y, y0.size() * 4, hipMemcpyDeviceToHost);
+            hipMemset(Y, 0, y0.size() * 4);
+            run10(X, W, Y, s.M, s.N, s.K, 1); hipMemcpy(y1.data(), Y, y1.size() * 4, hipMemcpyDeviceToHost);
+            size_t bad = 0; for (size_t i = 0; i < y0.size(); ++i) bad += y0[i] != y1[i];
+            printf("  LDS-DMA variant vs full loop: %zu of %zu outputs differ\n", bad, y0.size());
+        }
         printf("%-28s M=%d N=%d K=%d  (%d workgroups, %.2f per CU)\n", s.what, s.M, s.N, s.K, (s.M + 63) / 64 * (s.N / 64),
                (s.M + 63) / 64 * (s.N / 64) / 256.0);
         for (int round = 0; round < 2; ++round) {
-            float t7 = run<7>(X, W, Y, s.M, s.N, s.K, 10), t8 = run<8>(X, W, Y, s.M, s.N, s.K, 10), t9 = run9(X, W, Y, s.M, s.N, s.K, 10);
+            float t7 = run<7>(X, W, Y, s.M, s.N, s.K, 10), t8 = run<8>(X, W, Y, s.M, s.N, s.K, 10), t9 = run9(X, W, Y, s.M, s.N, s.K, 10), t10 = run10(X, W, Y, s.M, s.N, s.K, 10);
             float t[7] = {run<0>(X, W, Y, s.M, s.N, s.K, 10), run<1>(X, W, Y, s.M, s.N, s.K, 10), run<2>(X, W, Y, s.M, s.N, s.K, 10),
                           run<3>(X, W, Y, s.M, s.N, s.K, 10), run<4>(X, W, Y, s.M, s.N, s.K, 10), run<5>(X, W, Y, s.M, s.N, s.K, 10),
                           run<6>(X, W, Y, s.M, s.N, s.K, 10)};
-            printf("  round %d TFLOP/s: full %.1f | no-gload %.1f | no-lds-store %.1f | no-barrier %.1f | mfma+ldsread %.1f | mfma-only %.1f | 2-ahead %.1f | 16x16x4 mfma-only %.1f | 16x16x4 full %.1f | 32x64 tile, 2 waves %.1f\n",
-                   round, gflop / t[0], gflop / t[1], gflop / t[2], gflop / t[3], gflop / t[4], gflop / t[5], gflop / t[6], gflop / t7, gflop / t8, gflop / t9);
+            printf("  round %d TFLOP/s: full %.1f | no-gload %.1f | no-lds-store %.1f | no-barrier %.1f | mfma+ldsread %.1f | mfma-only %.1f | 2-ahead %.1f | 16x16x4 mfma-only %.1f | 16x16x4 full %.1f | 32x64 tile, 2 waves %.1f | LDS-DMA double buffer %.1f\n",
+                   round, gflop / t[0], gflop / t[1], gflop / t[2], gflop / t[3], gflop / t[4], gflop / t[5], gflop / t[6], gflop / t7, gflop / t8, gflop / t9, gflop / t10);
         }
         hipFree(X); hipFree(W); hipFree(Y);
     }
