@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 32, /*wgrad_group*/ 2};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 32, /*wgrad3*/ 1, /*wgrad3_blocks*/ 768, /*wgrad_group*/ 2};
 
 namespace {
 int* tuning_slot(const char* name) {
@@ -14,6 +14,8 @@ int* tuning_slot(const char* name) {
     if (!strcmp(name, "bn_grid")) return &g_osi_tuning.bn_grid;
     if (!strcmp(name, "bn_single_p")) return &g_osi_tuning.bn_single_p;
     if (!strcmp(name, "wgrad_group")) return &g_osi_tuning.wgrad_group;
+    if (!strcmp(name, "wgrad3")) return &g_osi_tuning.wgrad3;
+    if (!strcmp(name, "wgrad3_blocks")) return &g_osi_tuning.wgrad3_blocks;
     return nullptr;
 }
 }  // namespace
@@ -23,7 +25,7 @@ int osi_abi_version(void) { return 2; }
 int osi_set_tuning(const char* name, int value) {
     int* s = tuning_slot(name);
     if (!s) return OSI_ERR_ARG;
-    if (s == &g_osi_tuning.wgrad_blocks && value < 1) return OSI_ERR_ARG;
+    if ((s == &g_osi_tuning.wgrad_blocks || s == &g_osi_tuning.wgrad3_blocks) && value < 1) return OSI_ERR_ARG;
     if (s == &g_osi_tuning.wgrad_nst && value != 1 && value != 2) return OSI_ERR_ARG;
     if (s == &g_osi_tuning.bn_grid && value < 1) return OSI_ERR_ARG;
     if (s == &g_osi_tuning.bn_single_p && value < 1) return OSI_ERR_ARG;

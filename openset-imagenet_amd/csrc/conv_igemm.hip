@@ -904,6 +904,142 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 3 : (WM * WN == 2 ?
         }
 }
 
+// ======================================================================================================
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution with ALL NINE TAPS in one workgroup.
+// The per-tap kernel above streams the dY tile once per tap (nine workgroups per cell). Here one workgroup owns a (64 cout x 32 cin)
+// cell of a K split and walks the split's pixels in runs of 32: per run it stages the dY rows ONCE and ONE window of X rows
+// (32 + 2W + 2 flattened pixels: for stride 1 / pad 1 the input pixel of (output pixel q, tap r,s) is q + (r-1) W + (s-1) in the SAME
+// flattened index, so a tap is a constant row shift inside the window) and feeds nine accumulator sets from them. The image-border
+// zero padding is a 9-bit validity mask per pixel (built per run, one table read per K step) applied to the X operand.
+// MFMA: v_mfma_f32_16x16x4_f32 (same exact-fp32 rate as 32x32x2) so that a wave's 32 cout x 16 cin tile x 9 taps fits 72 accumulator
+// registers; the 18 MFMAs of a K step are independent (no accumulator latency exposed). dY traffic / 9, X traffic / (9 / window
+// amplification), LDS reads 12 per 18 MFMAs.
+// ======================================================================================================
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+constexpr int W3_BKP = 32;                 // pixels per K tile
+constexpr int W3_LDA = 64 + 16;            // dY image row stride (floats): 16 consecutive cout x 4 pixels per ds_read_b32 -> two pixel rows
+constexpr int W3_LDB = 32 + 16;            //   land on disjoint bank halves when the stride is 16 mod 32
+template <int NWIN, bool XF>               // NWIN: window passes of 32 rows (2: W <= 15, 3: W <= 31, 5: W <= 63)
+__global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accumulator + staging registers: 3 waves per SIMD, no spills
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn2 = wave >> 1, wc = wave & 1;
+    const int W = p.W, WIN = W3_BKP + 2 * W + 2;
+    float* sA = smem;                                   // [32][W3_LDA]  dY rows of the run
+    float* sB = sA + W3_BKP * W3_LDA;                   // [WIN][W3_LDB] X window
+    uint32_t* sM = reinterpret_cast<uint32_t*>(sB + NWIN * 32 * W3_LDB);   // [32] tap-validity bits per pixel of the run
+    // block -> (cout tile, cin tile, split): whole K splits per XCD (see k_conv_wgrad)
+    const int ctiles = p.Cin / 32;
+    int mt, ct, split;
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int u = slot % p.ginner, key = (slot / p.ginner) * 8 + xcd;
+        if (key >= p.gkeys) return;
+        if (p.gkind == 0) { split = key; mt = u % p.MT; ct = u / p.MT; }
+        else { mt = key % p.MT; const int rest = key / p.MT; ct = rest % ctiles; split = rest / ctiles; }
+    }
+    const int n0 = mt * 64, c0 = ct * 32;
+    const int kbeg = split * p.kchunk, kend = min(p.M, kbeg + p.kchunk);
+    const int T = kend > kbeg ? (kend - kbeg + W3_BKP - 1) / W3_BKP : 0;
+
+    f32x4acc acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[t][i] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rdy = make_rsrc(p.w, p.w_bytes);
+    const int a_row = tid >> 4, a_c4 = tid & 15;        // dY: 16 float4 per pixel row, 16 rows per pass, 2 passes
+    const int b_row = tid >> 3, b_c4 = tid & 7;         // X window: 8 float4 per row, 32 rows per pass, NWIN passes
+    f32x4 ra[2], rb[NWIN];
+    f32x4 xsc = {0, 0, 0, 0}, xsh = xsc;
+    if (XF) { xsc = ld4(p.in_scale + c0 + b_c4 * 4); xsh = ld4(p.in_shift + c0 + b_c4 * 4); }
+
+    auto gload = [&](int t) {
+        const int q0 = kbeg + t * W3_BKP;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {      // rows past the split's end read as zero (sentinel offset): their products vanish
+            const int q = q0 + a_row + 16 * i;
+            ra[i] = bld4(rdy, q < kend ? (uint32_t)(((a_row + 16 * i) * p.Cout + n0 + a_c4 * 4) * 4) : OOB, (uint32_t)q0 * p.Cout * 4);
+        }
+        const long wq0 = (long)q0 - W - 1;  // flattened input pixel of window row 0 (negative / past the end: range check -> zeros, masked anyway)
+#pragma unroll
+        for (int i = 0; i < NWIN; ++i) {
+            const int j = b_row + 32 * i;
+            const long wq = wq0 + j;
+            const bool in = j < WIN && wq >= 0 && wq < (long)p.M;
+            rb[i] = bld4(rx, in ? (uint32_t)((wq * p.Cin + c0 + b_c4 * 4) * 4) : OOB, 0);
+        }
+    };
+    auto sstore = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(sA + (a_row + 16 * i) * W3_LDA + a_c4 * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NWIN; ++i) {
+            f32x4 v = rb[i];
+            if (XF) {      // fused input activation; rows outside the tensor become relu(shift) garbage, which the tap mask removes
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], xsc[e], xsh[e]), 0.f);
+            }
+            *reinterpret_cast<f32x4*>(sB + (b_row + 32 * i) * W3_LDB + b_c4 * 4) = v;
+        }
+        if (tid < W3_BKP) {                 // tap validity of pixel q: bit (3 r + s) set when (h + r - 1, w + s - 1) is inside the image
+            const int q = kbeg + t * W3_BKP + tid;
+            uint32_t bits = 0;
+            if (q < kend) {
+                const uint32_t b = fdiv((uint32_t)q, p.dHoWo);
+                const uint32_t rem = (uint32_t)q - b * p.dHoWo.d;
+                const int h = (int)fdiv(rem, p.dWo), w = (int)(rem - fdiv(rem, p.dWo) * p.dWo.d);
+                const uint32_t rowm = (h > 0 ? 1u : 0u) | 2u | (h < p.H - 1 ? 4u : 0u);     // r = 0, 1, 2
+                const uint32_t colm = (w > 0 ? 1u : 0u) | 2u | (w < p.W - 1 ? 4u : 0u);     // s = 0, 1, 2
+#pragma unroll
+                for (int r = 0; r < 3; ++r) if ((rowm >> r) & 1) bits |= colm << (3 * r);
+            }
+            sM[tid] = bits;
+        }
+    };
+
+    const int l15 = lane & 15, lk = lane >> 4;
+    if (T > 0) {
+        gload(0);
+        sstore(0);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) gload(t + 1);
+#pragma unroll 1      // keep the K steps rolled: unrolled, the scheduler hoists every LDS read of the run and spills the accumulators
+            for (int ks = 0; ks < W3_BKP / 4; ++ks) {
+                const int kp = 4 * ks + lk;                    // this lane's pixel of the K step
+                const float a0 = sA[kp * W3_LDA + 32 * wn2 + l15], a1 = sA[kp * W3_LDA + 32 * wn2 + 16 + l15];
+                const uint32_t m = sM[kp];
+                const float* bp = sB + kp * W3_LDB + 16 * wc + l15;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        float b = bp[(r * W + s) * W3_LDB];
+                        b = (m >> (3 * r + s)) & 1 ? b : 0.f;
+                        acc[3 * r + s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[3 * r + s][0], 0, 0, 0);
+                        acc[3 * r + s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[3 * r + s][1], 0, 0, 0);
+                    }
+            }
+            __syncthreads();                 // every wave is done reading the run
+            if (t + 1 < T) sstore(t + 1);
+            __syncthreads();
+        }
+    }
+    // C/D of 16x16x4: column (cin) = lane & 15, row (cout) = (lane >> 4) * 4 + reg
+    float* out = p.y + (size_t)split * p.slab_stride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = n0 + 32 * wn2 + 16 * i + lk * 4 + e;
+                out[(size_t)row * p.Ktot + t * p.Cin + c0 + 16 * wc + l15] = acc[t][i][e];
+            }
+}
+
 // out[i] = sum_s slab[s][i]  (fixed order: bitwise reproducible)
 // One workgroup = 16 consecutive float4 outputs x 16 split lanes: lane j sums splits j, j+16, ... (4 independent loads in
 // flight), then the 16 lane partials are added in lane order. Many small dependent-latency chains instead of one long one.
@@ -1055,6 +1191,46 @@ static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
     }
     OSI_LAUNCH_CHECK();
     return OSI_OK;
+}
+
+// all-taps 3x3 weight gradient: eligibility, split plan, launch
+static bool wgrad3_ok(const osi_conv_desc* d) {
+    return g_osi_tuning.wgrad3 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 32 == 0 && d->Cout % 64 == 0 &&
+           d->W <= 63;
+}
+static void plan_wgrad3(const osi_conv_desc* d, int& splits, int& kchunk) {
+    const long cells = (long)(d->Cout / 64) * (d->Cin / 32);
+    const long M = (long)d->B * d->Ho * d->Wo;
+    // four 256-thread workgroups per CU (register budget of the nine accumulator sets) fill the machine; as for the per-tap kernel
+    // the side stream gets half of that by default
+    long s = (g_osi_tuning.wgrad3_blocks + cells - 1) / cells;
+    const long maxs = (M + 8 * W3_BKP - 1) / (8 * W3_BKP);
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s >= 8) { long r8 = (s + 4) / 8 * 8; if (r8 > maxs) r8 = maxs / 8 * 8; if (r8 >= 8) s = r8; }
+    long chunk = ((M + s - 1) / s + W3_BKP - 1) / W3_BKP * W3_BKP;
+    splits = (int)((M + chunk - 1) / chunk); kchunk = (int)chunk;
+}
+template <int NWIN, bool XF>
+static int launch_wgrad3_n(ConvP p, int splits, hipStream_t st) {
+    p.MT = p.Cout / 64;
+    const int ctiles = p.Cin / 32;
+    p.splits = splits;
+    if (splits >= 8) { p.gkind = 0; p.gkeys = splits; p.ginner = p.MT * ctiles; }
+    else { p.gkind = 3; p.gkeys = p.MT * ctiles * splits; p.ginner = 1; }
+    const size_t smem = ((size_t)W3_BKP * W3_LDA + (size_t)NWIN * 32 * W3_LDB + 32) * sizeof(float);
+    if (int e = set_smem(k_conv_wgrad3<NWIN, XF>, smem)) return e;
+    const long grid = ((long)p.gkeys + 7) / 8 * 8 * p.ginner;
+    hipLaunchKernelGGL((k_conv_wgrad3<NWIN, XF>), dim3((unsigned)grid), dim3(256), smem, st, p);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+template <bool XF>
+static int launch_wgrad3(const ConvP& p, int splits, hipStream_t st) {
+    const int win = W3_BKP + 2 * p.W + 2;
+    if (win <= 64) return launch_wgrad3_n<2, XF>(p, splits, st);
+    if (win <= 96) return launch_wgrad3_n<3, XF>(p, splits, st);
+    return launch_wgrad3_n<5, XF>(p, splits, st);
 }
 
 // wgrad geometry shared by the workspace query and the launcher
@@ -1265,6 +1441,7 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
 size_t osi_conv_wgrad_workspace(const osi_conv_desc* d) {
     if (!desc_ok(d)) return 0;
     WgradPlan w = plan_wgrad(d);
+    if (wgrad3_ok(d)) plan_wgrad3(d, w.splits, w.kchunk);
     const size_t n = (size_t)d->Cout * (is_stem(d) ? 224 : d->R * d->S * d->Cin);
     return w.splits > 1 ? (size_t)w.splits * n * sizeof(float) : 0;
 }
@@ -1291,6 +1468,8 @@ static int conv_wgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     OSI_REQUIRE(d->Cout % 64 == 0 && (stem || d->Cin % 64 == 0));
     hipStream_t st = (hipStream_t)stream;
     WgradPlan w = plan_wgrad(d);
+    const bool all_taps = !stem && wgrad3_ok(d);
+    if (all_taps) plan_wgrad3(d, w.splits, w.kchunk);
     ConvP p = make_p(d);
     const size_t n = (size_t)d->Cout * p.Ktot;
     OSI_REQUIRE(n % 4 == 0);
@@ -1305,7 +1484,8 @@ static int conv_wgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     // Single-buffered LDS by default (as in fwd/dgrad: twice the resident workgroups beat staging depth): 11.4 -> 10.3 ms per step
     // for the wgrad class and -0.45 ms on the overlapped step, measured with the side-stream schedule of the executor.
     const int nst = g_osi_tuning.wgrad_nst;
-    if (in_scale) {   // fused input activation: single-buffered forms only (the ones the executor uses)
+    if (all_taps) e = in_scale ? launch_wgrad3<true>(p, w.splits, st) : launch_wgrad3<false>(p, w.splits, st);
+    else if (in_scale) {   // fused input activation: single-buffered forms only (the ones the executor uses)
         if (w.wm == 2 && w.wn == 2) e = launch_wgrad<2, 2, false, 1, true>(p, w.splits, st);
         else if (w.wm == 2) e = launch_wgrad<2, 1, false, 1, true>(p, w.splits, st);
         else if (w.wn == 2) e = launch_wgrad<1, 2, false, 1, true>(p, w.splits, st);
