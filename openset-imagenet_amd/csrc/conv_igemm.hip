@@ -1006,21 +1006,45 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
         __syncthreads();
         for (int t = 0; t < T; ++t) {
             if (t + 1 < T) gload(t + 1);
-#pragma unroll 1      // keep the K steps rolled: unrolled, the scheduler hoists every LDS read of the run and spills the accumulators
-            for (int ks = 0; ks < W3_BKP / 4; ++ks) {
+            // K steps of 4 pixels, software-pipelined by hand: the 12 LDS reads of step k+1 are issued before the 18 MFMAs of step k
+            // (two register sets, ping-pong). Left to itself the compiler either waits for each read right before its MFMA (rolled
+            // loop) or hoists every read of the run and spills the accumulators (unrolled loop).
+            struct Ops { float a0, a1, b[9]; uint32_t m; };
+            auto lds_ops = [&](int ks, Ops& o) {
                 const int kp = 4 * ks + lk;                    // this lane's pixel of the K step
-                const float a0 = sA[kp * W3_LDA + 32 * wn2 + l15], a1 = sA[kp * W3_LDA + 32 * wn2 + 16 + l15];
-                const uint32_t m = sM[kp];
+                o.a0 = sA[kp * W3_LDA + 32 * wn2 + l15]; o.a1 = sA[kp * W3_LDA + 32 * wn2 + 16 + l15];
+                o.m = sM[kp];
                 const float* bp = sB + kp * W3_LDB + 16 * wc + l15;
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) {
-                        float b = bp[(r * W + s) * W3_LDB];
-                        b = (m >> (3 * r + s)) & 1 ? b : 0.f;
-                        acc[3 * r + s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[3 * r + s][0], 0, 0, 0);
-                        acc[3 * r + s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[3 * r + s][1], 0, 0, 0);
-                    }
+                    for (int s = 0; s < 3; ++s) o.b[3 * r + s] = bp[(r * W + s) * W3_LDB];
+            };
+            auto mma_ops = [&](const Ops& o) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const float b = (o.m >> tp) & 1 ? o.b[tp] : 0.f;
+                    acc[tp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0, b, acc[tp][0], 0, 0, 0);
+                    acc[tp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1, b, acc[tp][1], 0, 0, 0);
+                }
+            };
+            if constexpr (NWIN < 5) {
+                Ops o0, o1;
+                lds_ops(0, o0);
+#pragma unroll 1
+                for (int ks = 0; ks < W3_BKP / 4; ks += 2) {
+                    lds_ops(ks + 1, o1);
+                    mma_ops(o0);
+                    if (ks + 2 < W3_BKP / 4) lds_ops(ks + 2, o0);
+                    mma_ops(o1);
+                }
+            } else {     // the widest window (W > 31) stages 20 registers of X rows: no room for a second operand set
+#pragma unroll 1
+                for (int ks = 0; ks < W3_BKP / 4; ++ks) {
+                    Ops o;
+                    lds_ops(ks, o);
+                    mma_ops(o);
+                }
             }
             __syncthreads();                 // every wave is done reading the run
             if (t + 1 < T) sstore(t + 1);

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -28,7 +29,11 @@ __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, u
 
 template <int V>
 __global__ __launch_bounds__(256, V == 6 ? 6 : 8) void k_gemm(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int M,
-                                                int N, int K, int MT, int NT) {
+                                                int N, int K, int MT, int NT, unsigned long long* stamps = nullptr) {
+    // diagnostic clock read (MI355X_MICROARCH.md 'DVFS give-back' item 6): shader cycles / 100 MHz real-time ticks around the whole
+    // workgroup; only when a stamp buffer is passed (a separate launch, never a timed one)
+    unsigned long long c0 = 0, r0 = 0;
+    if (stamps) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
@@ -130,6 +135,10 @@ __global__ __launch_bounds__(256, V == 6 ? 6 : 8) void k_gemm(const float* __res
     }
     if (V == 7 || V == 8) {     // fold the four 16x16 accumulators into the store pattern below (layout irrelevant for timing)
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 4; ++r) acc[(i * 2 + j) * 4 + r] = acc4[i][j][r];
+    }
+    if (stamps && tid == 0) {
+        stamps[2 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+        stamps[2 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
     // epilogue as in the product kernel's generic path (enough to keep the accumulators alive)
     const int col = n0 + wn * 32 + (lane & 31);
@@ -283,6 +292,25 @@ static float run9(const float* X, const float* W, float* Y, int M, int N, int K,
 }
 
 template <int V>
+static double clock_ghz(const float* X, const float* W, float* Y, int M, int N, int K) {
+    const int MT = (M + 63) / 64, NT = N / 64;
+    const int grid = (MT + 7) / 8 * 8 * NT;
+    const size_t smem = (size_t)128 * LDR * sizeof(float);
+    unsigned long long* d;
+    hipMalloc(&d, (size_t)grid * 16); hipMemset(d, 0, (size_t)grid * 16);
+    for (int i = 0; i < 30; ++i) hipLaunchKernelGGL((k_gemm<V>), dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL((k_gemm<V>), dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT, d);      // hot: stamped launch after 30 back-to-back ones
+    std::vector<unsigned long long> h((size_t)grid * 2);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    hipFree(d);
+    std::vector<double> g;
+    for (int b = 0; b < grid; ++b) if (h[2 * b + 1] > 50) g.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1);   // cycles per 10 ns tick -> GHz
+    if (g.empty()) return 0;
+    std::sort(g.begin(), g.end());
+    return g[g.size() / 2];
+}
+
+template <int V>
 static float run(const float* X, const float* W, float* Y, int M, int N, int K, int reps) {
     const int MT = (M + 63) / 64, NT = N / 64;
     const int grid = (MT + 7) / 8 * 8 * NT;
@@ -323,6 +351,8 @@ int main() {
         }
         printf("%-28s M=%d N=%d K=%d  (%d workgroups, %.2f per CU)\n", s.what, s.M, s.N, s.K, (s.M + 63) / 64 * (s.N / 64),
                (s.M + 63) / 64 * (s.N / 64) / 256.0);
+        printf("  in-kernel clock (median over workgroups, after 30 back-to-back launches): full loop %.2f GHz | mfma-only %.2f GHz | no-gload %.2f GHz\n",
+               clock_ghz<0>(X, W, Y, s.M, s.N, s.K), clock_ghz<5>(X, W, Y, s.M, s.N, s.K), clock_ghz<1>(X, W, Y, s.M, s.N, s.K));
         for (int round = 0; round < 2; ++round) {
             float t7 = run<7>(X, W, Y, s.M, s.N, s.K, 10), t8 = run<8>(X, W, Y, s.M, s.N, s.K, 10), t9 = run9(X, W, Y, s.M, s.N, s.K, 10), t10 = run10(X, W, Y, s.M, s.N, s.K, 10);
             float t[7] = {run<0>(X, W, Y, s.M, s.N, s.K, 10), run<1>(X, W, Y, s.M, s.N, s.K, 10), run<2>(X, W, Y, s.M, s.N, s.K, 10),
