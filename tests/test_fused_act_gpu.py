@@ -190,3 +190,46 @@ def test_conv1_recomputes_the_previous_block_output(cuda, Cin, Cout, H, B, tile)
     # 3x3 / strided descriptors are refused: the input must be a block output feeding a 1x1 stride-1 conv
     d3 = N.ConvDesc.make(B, H, H, Cin, Cout, 3, 1, 1)
     assert L.osi_conv_fwd_act2(ctypes.byref(d3), N.ptr(y3), N.ptr(sc), N.ptr(sh), N.ptr(res), N.ptr(w), N.ptr(ys[0]), 0, None, 0, None, None, T.S()) == -1
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,B", [(32, 64, 1, 1, 7), (64, 64, 2, 3, 5), (32, 128, 5, 9, 3), (64, 64, 14, 14, 4), (96, 64, 7, 31, 2),
+                                            (64, 128, 28, 28, 3), (32, 64, 9, 56, 2), (64, 64, 6, 63, 1), (128, 192, 7, 7, 9)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_all_taps_3x3_weight_gradient(cuda, Cin, Cout, H, W, B, fused):
+    """k_conv_wgrad3 (one workgroup walks the nine taps of a stride-1 3x3 layer against one staged dY run and one X window): every
+    window-pass variant (W <= 15 / 31 / 63), images narrower than the filter, non-square images, ragged runs and split ends, with and
+    without the fused input activation — against torch's conv2d_weight in fp64, against the per-tap kernel (osi_set_tuning("wgrad3", 0))
+    and against itself (bitwise reproducible)."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(Cin + Cout + H * 7 + W)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 1.2).to(cuda)
+    dy = torch.randn(B, H, W, Cout, generator=g).to(cuda)
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).to(cuda), (torch.randn(Cin, generator=g) * 0.6).to(cuda)
+    d = N.ConvDesc(B, H, W, Cin, H, W, Cout, 3, 3, 1, 1)
+
+    def run():
+        nb = L.osi_conv_wgrad_workspace(ctypes.byref(d))
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=cuda)
+        dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=cuda)
+        if fused:
+            N.check(L.osi_conv_wgrad_act(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(dw), N.ptr(ws), nb, T.S()))
+        else:
+            N.check(L.osi_conv_wgrad(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(dw), N.ptr(ws), nb, T.S()))
+        return dw
+    v = ctypes.c_int()
+    assert L.osi_get_tuning(b"wgrad3", ctypes.byref(v)) == 0 and v.value == 1
+    a, a2 = run(), run()
+    N.check(L.osi_set_tuning(b"wgrad3", 0))
+    try:
+        per_tap = run()
+    finally:
+        N.check(L.osi_set_tuning(b"wgrad3", 1))
+    act = torch.relu(x.double() * sc.double() + sh.double()) if fused else x.double()
+    ref = torch.nn.grad.conv2d_weight(T.nchw(act), (Cout, Cin, 3, 3), T.nchw(dy.double()), 1, 1).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max()) + 1e-30
+    Kp = B * H * W
+    assert torch.isfinite(a).all() and torch.equal(a, a2)
+    assert float((a.double() - ref).abs().max()) <= (2e-6 + 6e-8 * Kp ** 0.5) * scale + 1e-6
+    assert float((a - per_tap).abs().max()) <= 2e-5 * scale
