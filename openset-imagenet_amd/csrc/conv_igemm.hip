@@ -1462,10 +1462,16 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     }
 }
 
+// shapes the weight-gradient kernels take: Cout in 64s; Cin in 64s (per-tap kernel), in 32s for the all-taps 3x3 form, 4 for the stem
+static bool wgrad_shape_ok(const osi_conv_desc* d) {
+    return d->Cout % 64 == 0 && (is_stem(d) || d->Cin % 64 == 0 || wgrad3_ok(d));
+}
+
 size_t osi_conv_wgrad_workspace(const osi_conv_desc* d) {
-    if (!desc_ok(d)) return 0;
-    WgradPlan w = plan_wgrad(d);
+    if (!desc_ok(d) || !wgrad_shape_ok(d)) return 0;
+    WgradPlan w{1, 1, 1, 0};
     if (wgrad3_ok(d)) plan_wgrad3(d, w.splits, w.kchunk);
+    else w = plan_wgrad(d);
     const size_t n = (size_t)d->Cout * (is_stem(d) ? 224 : d->R * d->S * d->Cin);
     return w.splits > 1 ? (size_t)w.splits * n * sizeof(float) : 0;
 }
@@ -1489,11 +1495,12 @@ static int conv_wgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     OSI_REQUIRE(desc_ok(d) && dy && x && dw);
     OSI_REQUIRE(!in_scale || !is_stem(d));
     const bool stem = is_stem(d);
-    OSI_REQUIRE(d->Cout % 64 == 0 && (stem || d->Cin % 64 == 0));
+    OSI_REQUIRE(wgrad_shape_ok(d));
     hipStream_t st = (hipStream_t)stream;
-    WgradPlan w = plan_wgrad(d);
     const bool all_taps = !stem && wgrad3_ok(d);
+    WgradPlan w{1, 1, 1, 0};
     if (all_taps) plan_wgrad3(d, w.splits, w.kchunk);
+    else w = plan_wgrad(d);
     ConvP p = make_p(d);
     const size_t n = (size_t)d->Cout * p.Ktot;
     OSI_REQUIRE(n % 4 == 0);

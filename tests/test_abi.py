@@ -37,6 +37,11 @@ def test_argument_validation_without_gpu():
     bad = N.ConvDesc(2, 8, 8, 64, 9, 9, 64, 3, 3, 1, 1)  # inconsistent output size
     assert lib.osi_conv_fwd(ctypes.byref(bad), 16, 16, 16, 0, None) == -1
     assert lib.osi_conv_fwd(ctypes.byref(d), None, None, None, 0, None) == -1
+    # weight-gradient shapes: input channels in 64s (32s only for the all-taps 3x3 stride-1 form); unsupported -> 0 bytes / OSI_ERR_ARG
+    lib.osi_conv_wgrad_workspace.restype = ctypes.c_size_t
+    assert lib.osi_conv_wgrad_workspace(ctypes.byref(N.ConvDesc.make(2, 8, 8, 32, 64, 1, 1, 0))) == 0
+    assert lib.osi_conv_wgrad(ctypes.byref(N.ConvDesc.make(2, 8, 8, 32, 64, 1, 1, 0)), 16, 16, 16, 16, 0, None) == -1
+    assert lib.osi_conv_wgrad_workspace(ctypes.byref(N.ConvDesc.make(64, 14, 14, 32, 64, 3, 1, 1))) > 0
     assert lib.osi_bn_apply(None, None, None, None, None, 4, 64, 1, None) == -1
     assert lib.osi_loss_fwd_bwd(7, 16, 16, 4, 4, 1.0, -1, None, None, 0, 0.0, 0.0, 16, 16, None, None) == -1
     assert lib.osi_adam_step(16, 16, 16, 16, 6, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) == -1   # n % 4 != 0

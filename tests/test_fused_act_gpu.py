@@ -221,15 +221,17 @@ def test_all_taps_3x3_weight_gradient(cuda, Cin, Cout, H, W, B, fused):
     v = ctypes.c_int()
     assert L.osi_get_tuning(b"wgrad3", ctypes.byref(v)) == 0 and v.value == 1
     a, a2 = run(), run()
-    N.check(L.osi_set_tuning(b"wgrad3", 0))
-    try:
-        per_tap = run()
-    finally:
-        N.check(L.osi_set_tuning(b"wgrad3", 1))
+    per_tap = None
+    if Cin % 64 == 0:                      # the per-tap kernel takes input channels in 64s only
+        N.check(L.osi_set_tuning(b"wgrad3", 0))
+        try:
+            per_tap = run()
+        finally:
+            N.check(L.osi_set_tuning(b"wgrad3", 1))
     act = torch.relu(x.double() * sc.double() + sh.double()) if fused else x.double()
     ref = torch.nn.grad.conv2d_weight(T.nchw(act), (Cout, Cin, 3, 3), T.nchw(dy.double()), 1, 1).permute(0, 2, 3, 1)
     scale = float(ref.abs().max()) + 1e-30
     Kp = B * H * W
     assert torch.isfinite(a).all() and torch.equal(a, a2)
     assert float((a.double() - ref).abs().max()) <= (2e-6 + 6e-8 * Kp ** 0.5) * scale + 1e-6
-    assert float((a - per_tap).abs().max()) <= 2e-5 * scale
+    assert per_tap is None or float((a - per_tap).abs().max()) <= 2e-5 * scale
