@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 32, /*wgrad3*/ 1, /*wgrad3_blocks*/ 768, /*wgrad_group*/ 2};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 32, /*wgrad3*/ 1, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2};
 
 namespace {
 int* tuning_slot(const char* name) {
@@ -15,6 +15,8 @@ int* tuning_slot(const char* name) {
     if (!strcmp(name, "bn_single_p")) return &g_osi_tuning.bn_single_p;
     if (!strcmp(name, "wgrad_group")) return &g_osi_tuning.wgrad_group;
     if (!strcmp(name, "wgrad3")) return &g_osi_tuning.wgrad3;
+    if (!strcmp(name, "fwd_wide")) return &g_osi_tuning.fwd_wide;
+    if (!strcmp(name, "dgrad_wide")) return &g_osi_tuning.dgrad_wide;
     if (!strcmp(name, "wgrad3_blocks")) return &g_osi_tuning.wgrad3_blocks;
     return nullptr;
 }

@@ -1372,6 +1372,7 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
         // 64x64 everywhere except the 7x7-spatial layers with few tiles, where the wider column tile halves the A re-reads
         const long tiles64 = ((long)p.M + 63) / 64 * (d->Cout / 64);
         tile = (tiles64 < 1024 && d->Cout % 128 == 0) ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
+        if (g_osi_tuning.fwd_wide && d->Cout % 128 == 0) tile = OSI_TILE_64x128_S1;   // A/B: wide tiles wherever the channel count allows
     }
     if (int e = with_stats(fwd_tile_rows(tile))) return e;
     if (in_scale) {   // fused input activation: built for the single-buffered 64-row tiles the executor uses
@@ -1431,7 +1432,7 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     p.w_bytes = (int)((size_t)d->Cout * p.Ktot * 4);
     // Measured (profiles/conv_layers_r01.txt and the full step): with buffer loads the 64x64 single-buffered tile wins or ties
     // on every ResNet-50 shape (the dgrad class went 12.1 -> 11.0 ms per step against the 64x128 rule used before).
-    if (tile == OSI_TILE_AUTO) tile = OSI_TILE_64x64_S1;
+    if (tile == OSI_TILE_AUTO) tile = (g_osi_tuning.dgrad_wide && d->Cin % 128 == 0) ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
     if (f) {
         OSI_REQUIRE(f->relu_mask || f->scale0 || !f->partials);
         OSI_REQUIRE(!f->scale0 || (!f->relu_mask && f->shift0 && f->y0));   // one gate source: the bitmask, or y0 * scale0 + shift0 > 0
