@@ -197,3 +197,17 @@ def test_metrics_module_matches_reference_vectors(cuda, golden_dir):
     ps, pc = s.max(1)
     pc = pc.clone(); pc[(f.norm(dim=1) * ps) < 0.8] = -1
     assert torch.equal(out[:, 0].long(), pc) and torch.allclose(out[:, 1], ps, atol=1e-6)
+
+
+def test_predict_objectosphere_matches_reference_vectors(cuda, golden_dir):
+    """metrics.predict_objectosphere against vectors produced by the reference's own function (metrics.py:45-62;
+    tests/golden/make_golden_misc.py): identical predicted classes (incl. the -1 rejections), scores to fp32 rounding."""
+    import os
+    from openset_imagenet import metrics
+    G = np.load(os.path.join(golden_dir, "misc_reference.npz"))
+    for name in G["po.names"]:
+        z, f = torch.from_numpy(G[f"po.{name}.logits"]).to(cuda), torch.from_numpy(G[f"po.{name}.features"]).to(cuda)
+        out = metrics.predict_objectosphere(z, f, float(G[f"po.{name}.threshold"])).cpu().numpy()
+        ref = G[f"po.{name}.result"]
+        assert out.shape == ref.shape and np.array_equal(out[:, 0], ref[:, 0]), name
+        assert np.allclose(out[:, 1], ref[:, 1], rtol=2e-6, atol=1e-7), name

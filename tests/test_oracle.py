@@ -177,3 +177,30 @@ def test_oracle_body_matches_transformers_witness(golden_dir):
         work = {k: v.clone() for k, v in sd.items()}
         lg32, _ = R.forward(work, x.float(), True)
         assert float(np.abs(lg32.double().numpy() - W[f"{tag}.train.logits"]).max()) <= 1e-4
+
+
+def test_host_classes_match_reference_traces(golden_dir, tmp_path):
+    """AverageMeter / EarlyStopping (reference losses.py:32-94) and NameSpace / load_yaml (util.py:16-34) of the drop-in package against
+    traces produced by executing the reference's own classes (tests/golden/make_golden_misc.py): same values after every update /
+    call, same repr, same dict() and dump() of a loaded configuration."""
+    import openset_imagenet as oi
+    G = np.load(os.path.join(golden_dir, "misc_reference.npz"))
+    m = oi.AverageMeter()
+    for (v, c), ref in zip(G["am.updates"], G["am.trace"]):
+        m.update(float(v), int(c))
+        assert (m.val, m.avg, m.sum, m.count) == tuple(ref)
+    assert repr(m) == str(G["am.repr"])
+    m.reset()
+    assert [m.val, m.avg, m.sum, m.count] == list(G["am.after_reset"])
+    for tag in G["es.names"]:
+        patience, delta, loss_mode = G[f"es.{tag}.args"]
+        es = oi.EarlyStopping(patience=int(patience), delta=float(delta))
+        for v, (counter, best, stop) in zip(G[f"es.{tag}.values"], G[f"es.{tag}.trace"]):
+            es(float(v), loss=bool(loss_mode))
+            assert (es.counter, es.best_score, float(es.early_stop)) == (counter, best, stop), tag
+    y = tmp_path / "c.yaml"
+    y.write_text(str(G["ns.yaml_text"]))
+    cfg = oi.util.load_yaml(y)
+    assert cfg.dump() == str(G["ns.dump"]) and repr(cfg.dict()) == str(G["ns.dict_repr"])
+    assert cfg.loss.type == str(G["ns.loss_type"]) and cfg.opt.lr == float(G["ns.lr"]) and (cfg.gpu is None) == bool(G["ns.gpu_is_none"])
+    assert cfg.dist.distributed is True and cfg.parallel is False and cfg.checkpoint is None
