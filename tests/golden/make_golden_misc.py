@@ -61,7 +61,7 @@ def main():
     losses = load_reference("losses")
     g = torch.Generator().manual_seed(77)
     names = []
-    for name, B, C, thr, fscale in (("c30", 24, 30, 0.5, 1.0), ("c116_low", 16, 116, 0.05, 0.3), ("c152_high", 12, 152, 3.0, 2.0), ("one", 1, 5, 0.7, 1.0)):
+    for name, B, C, thr, fscale in (("c30", 24, 30, 1.7, 1.0), ("c116_low", 16, 116, 0.45, 0.3), ("c152_high", 12, 152, 3.0, 2.0), ("one", 1, 5, 0.7, 1.0)):
         z = torch.randn(B, C, generator=g) * 2
         f = torch.randn(B, C, generator=g) * fscale
         r = metrics.predict_objectosphere(z.clone(), f.clone(), thr)
