@@ -1,0 +1,112 @@
+"""The loop contract against the reference's OWN loops: tests/golden/loop_reference.npz holds what `train()`, `validate()` and
+`get_arrays()` of reference openset_imagenet/train.py:104-234 produced (executed in place by tests/golden/make_golden_loop.py) on
+a small (logits, features) model — tracker values, parameters after each epoch, validation confidences, the gathered arrays.
+
+CPU: this package's train() is model-agnostic above the kernels; with the same torch model, torch.nn.CrossEntropyLoss and torch
+optimizer it must reproduce the reference's trackers and parameters exactly (same operations in the same order).
+GPU: the same loops with this package's HIP losses, confidence kernel and softmax, within fp32 tolerance of the CPU reference.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from openset_imagenet import losses as L, tools
+from openset_imagenet.train import get_arrays, train, validate
+from openset_imagenet.util import NameSpace
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loop_reference.npz")
+
+
+class TinyNet(torch.nn.Module):
+    """The model make_golden_loop.py ran the reference loops on: forward -> (logits, features), `.logits` is a Linear."""
+
+    def __init__(self, hw, feat, n_out):
+        super().__init__()
+        self.body = torch.nn.Linear(3 * hw * hw, feat)
+        self.bn = torch.nn.BatchNorm1d(feat)
+        self.logits = torch.nn.Linear(feat, n_out)
+
+    def forward(self, x):
+        f = torch.relu(self.bn(self.body(x.flatten(1))))
+        return self.logits(f), f
+
+
+class Loader(list):
+    def __init__(self, batches):
+        super().__init__(batches)
+        self.dataset = range(sum(int(y.shape[0]) for _, y in batches))
+
+
+def _case(g, name):
+    C, F, HW, B = (int(v) for v in g["dims"])
+    n = len(g["sizes"])
+    model = TinyNet(HW, F, C)
+    model.load_state_dict({k[len(name) + 6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + ".init.")})
+    tr = [(torch.from_numpy(g[f"{name}.train.x{i}"]), torch.from_numpy(g[f"{name}.train.y{i}"])) for i in range(n)]
+    va = [(torch.from_numpy(g[f"{name}.val.x{i}"]), torch.from_numpy(g[f"{name}.val.y{i}"])) for i in range(n)]
+    loss_type, opt_type, epochs = (str(v) for v in g[f"{name}.meta"])
+    cfg = NameSpace({"parallel": True, "batch_size": B, "loss": {"type": loss_type}})
+    return model, tr, va, loss_type, opt_type, int(epochs), cfg, C
+
+
+def _optimizer(opt_type, model):
+    if opt_type == "adam":
+        return torch.optim.Adam(params=model.parameters(), lr=1e-2)
+    return torch.optim.SGD(params=model.parameters(), lr=1e-2, momentum=0.9)
+
+
+def _meter(m):
+    return np.array([m.val, m.avg, m.sum, m.count], dtype=np.float64)
+
+
+@pytest.mark.parametrize("name", ["softmax_sgd", "garbage_adam"])
+def test_train_loop_reproduces_the_reference_loop_exactly(name):
+    g = np.load(GOLD)
+    model, tr, _, loss_type, opt_type, epochs, cfg, C = _case(g, name)
+    tools.set_device_cpu()
+    loss_fn = torch.nn.CrossEntropyLoss(ignore_index=-1) if loss_type == "softmax" else \
+        torch.nn.CrossEntropyLoss(weight=torch.from_numpy(g[f"{name}.class_weights"]))       # reference train.py:343-347
+    opt = _optimizer(opt_type, model)
+    trackers = {"j": L.AverageMeter()}
+    trackers["j"].update(123.0, 7)            # train() resets the trackers first (train.py:115-116)
+    for e in range(epochs):
+        train(model, Loader(tr), opt, loss_fn, trackers, cfg)
+        assert model.training                  # train.py:125
+        np.testing.assert_array_equal(_meter(trackers["j"]), g[f"{name}.epoch{e}.train_j"])
+        for k, v in model.state_dict().items():
+            np.testing.assert_array_equal(v.numpy(), g[f"{name}.epoch{e}.state.{k}"], err_msg=f"{name} epoch {e} {k}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["entropic_adam", "softmax_sgd", "garbage_adam"])
+def test_loops_with_hip_losses_match_the_reference_loops(cuda, name):
+    g = np.load(GOLD)
+    model, tr, va, loss_type, opt_type, epochs, cfg, C = _case(g, name)
+    tools.set_device_gpu(0)
+    model = tools.device(model)
+    if loss_type == "entropic":
+        loss_fn = L.EntropicOpensetLoss(C, 1.0)
+    elif loss_type == "softmax":
+        loss_fn = L.SoftmaxLoss(ignore_index=-1)
+    else:
+        loss_fn = L.GarbageLoss(torch.from_numpy(g[f"{name}.class_weights"]).cuda())
+    opt = _optimizer(opt_type, model)
+    t_tr = {"j": L.AverageMeter()}
+    t_va = {"j": L.AverageMeter(), "conf_kn": L.AverageMeter(), "conf_unk": L.AverageMeter()}
+    tol = dict(rtol=2e-4, atol=2e-5)          # fp32 on two devices through up to ten optimizer steps at lr 1e-2
+    for e in range(epochs):
+        train(model, Loader(tr), opt, loss_fn, t_tr, cfg)
+        np.testing.assert_allclose(_meter(t_tr["j"]), g[f"{name}.epoch{e}.train_j"], **tol)
+        validate(model, Loader(va), loss_fn, C, t_va, cfg)
+        assert not model.training              # train.py:166
+        for k in t_va:
+            np.testing.assert_allclose(_meter(t_va[k]), g[f"{name}.epoch{e}.val_{k}"], err_msg=f"{name} epoch {e} {k}", **tol)
+        for k, v in model.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), g[f"{name}.epoch{e}.state.{k}"], err_msg=f"{name} epoch {e} {k}", **tol)
+    arrays = get_arrays(model, Loader(va))
+    for k, a in zip(("targets", "logits", "features", "scores"), arrays):
+        ref = g[f"{name}.arrays.{k}"]
+        assert a.shape == ref.shape and a.dtype == ref.dtype, k
+        np.testing.assert_allclose(a, ref, err_msg=f"{name} arrays {k}", **tol)
