@@ -33,7 +33,8 @@ class TinyNet(torch.nn.Module):
 
     def __init__(self, n_out):
         super().__init__()
-        self.body = torch.nn.Linear(3 * HW * HW, F)
+        self.body = torch.nn.Linear(3 * HW * HW, F, bias=False)   # like the convolutions in front of the real batch norms:
+        # a bias there has a mathematically zero gradient, and Adam would turn its rounding noise into lr-sized steps
         self.bn = torch.nn.BatchNorm1d(F)          # train()/eval() must matter, as with the real network
         self.logits = torch.nn.Linear(F, n_out)
 

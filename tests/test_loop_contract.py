@@ -24,7 +24,7 @@ class TinyNet(torch.nn.Module):
 
     def __init__(self, hw, feat, n_out):
         super().__init__()
-        self.body = torch.nn.Linear(3 * hw * hw, feat)
+        self.body = torch.nn.Linear(3 * hw * hw, feat, bias=False)
         self.bn = torch.nn.BatchNorm1d(feat)
         self.logits = torch.nn.Linear(feat, n_out)
 
@@ -95,7 +95,7 @@ def test_loops_with_hip_losses_match_the_reference_loops(cuda, name):
     opt = _optimizer(opt_type, model)
     t_tr = {"j": L.AverageMeter()}
     t_va = {"j": L.AverageMeter(), "conf_kn": L.AverageMeter(), "conf_unk": L.AverageMeter()}
-    tol = dict(rtol=2e-4, atol=2e-5)          # fp32 on two devices through up to ten optimizer steps at lr 1e-2
+    tol = dict(rtol=1e-3, atol=1e-4)          # fp32 on two devices through up to ten Adam steps at lr 1e-2; a contract slip (mode, reset, counts) is orders larger
     for e in range(epochs):
         train(model, Loader(tr), opt, loss_fn, t_tr, cfg)
         np.testing.assert_allclose(_meter(t_tr["j"]), g[f"{name}.epoch{e}.train_j"], **tol)
