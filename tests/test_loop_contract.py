@@ -110,3 +110,47 @@ def test_loops_with_hip_losses_match_the_reference_loops(cuda, name):
         ref = g[f"{name}.arrays.{k}"]
         assert a.shape == ref.shape and a.dtype == ref.dtype, k
         np.testing.assert_allclose(a, ref, err_msg=f"{name} arrays {k}", **tol)
+
+
+# ---- checkpoints: a file written by the reference's own save_checkpoint (tests/golden/make_golden_checkpoint.py) --------------------
+def _structure(obj):
+    if isinstance(obj, torch.Tensor):
+        return ["tensor", str(obj.dtype), list(obj.shape)]
+    if isinstance(obj, dict):
+        return {str(k): _structure(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_structure(v) for v in obj]
+    return type(obj).__name__
+
+
+def test_resume_from_a_checkpoint_written_by_the_reference(tmp_path):
+    import json
+    from openset_imagenet.train import load_checkpoint, save_checkpoint
+    from oracle import losses_oracle as LO
+    gdir = os.path.dirname(GOLD)
+    meta = json.load(open(os.path.join(gdir, "checkpoint_reference.json")))
+    inp = np.load(os.path.join(gdir, "checkpoint_reference_inputs.npz"))
+    g = np.load(GOLD)
+    C, F, HW, B = (int(v) for v in g["dims"])
+    tools.set_device_cpu()
+    model = TinyNet(HW, F, C)
+    opt = torch.optim.Adam(params=model.parameters(), lr=1e-2)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+    epoch, best = load_checkpoint(model, os.path.join(gdir, "checkpoint_reference.pth"), opt, sched)      # reference train.py:63-101
+    assert (epoch, best) == (1, 1.375) and sched.last_epoch == 1
+    assert opt.param_groups[0]["lr"] == float(inp["lr_after_resume"]) == 5e-3
+    # this package's save_checkpoint writes the same nested structure the reference's wrote, and (recorded at generation time) the
+    # reference's load_checkpoint read such a file back with every tensor equal
+    f = tmp_path / "ours.pth"
+    save_checkpoint(f, model, 0, opt, 1.375, sched)
+    assert _structure(torch.load(f, weights_only=False)) == meta["structure_reference_file"] == meta["structure_our_file"]
+    assert meta["reference_reads_our_file"] == {"epoch": 1, "best_score": 1.375, "model_equal": True, "optimizer_equal": True,
+                                                "scheduler_last_epoch": 1}
+    # the resumed run continues exactly where the reference's own run went (same batches, entropic loss from the oracle)
+    n = len(g["sizes"])
+    tr = [(torch.from_numpy(inp[f"x{i}"]), torch.from_numpy(inp[f"y{i}"])) for i in range(n)]
+    trackers = {"j": L.AverageMeter()}
+    train(model, Loader(tr), opt, lambda z, y: LO.entropic_openset_loss(z, y, 1.0), trackers, NameSpace({"parallel": True}))
+    np.testing.assert_allclose(_meter(trackers["j"]), inp["after_train_j"], rtol=1e-6)
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), inp[f"after.{k}"], rtol=1e-5, atol=1e-7, err_msg=k)
