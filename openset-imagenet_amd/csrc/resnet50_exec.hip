@@ -150,8 +150,13 @@ struct osi_resnet50 {
     bool side_prio_normal = false;   // side stream at default instead of lowest priority (read when the stream is created)
     const float* x4_ext = nullptr;   // external NHWC4 input bound by osi_resnet50_bind_input_nhwc4 (consumed by one forward)
     const float* x4_cur = nullptr;   // input of the step in flight (forward sets it, the stem weight gradient reads it)
+    bool stagger = false;            // option "stagger": a weight gradient starts when the input gradient of the SAME layer has finished
+                                     // (beside the next BatchNorm-backward kernels) and the next input gradient waits for it: matrix-bound
+                                     // kernels never co-run, only HBM-bound work overlaps them. A/B against the default co-running schedule.
+    struct PendingW { bool on = false; int ci = 0, gi = 0, in_bn = -1; const float* conv_in = nullptr; float* grads = nullptr; float* ws = nullptr; } pend;
+    bool w_inflight = false;
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wdone = nullptr;
     hipEvent_t buf_ev[NSCR] = {};
     bool buf_pending[NSCR] = {};
     bool side_dirty = false;
@@ -163,6 +168,7 @@ struct osi_resnet50 {
         if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio) != hipSuccess) return OSI_ERR_LAUNCH;
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
         if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&ev_wdone, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
         for (int i = 0; i < NSCR; ++i)
             if (hipEventCreateWithFlags(&buf_ev[i], hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
         return OSI_OK;
@@ -193,7 +199,7 @@ struct osi_resnet50 {
         for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
         if (side) {
             (void)hipStreamSynchronize(side);
-            (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join);
+            (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_wdone);
             for (int i = 0; i < NSCR; ++i) (void)hipEventDestroy(buf_ev[i]);
             (void)hipStreamDestroy(side);
         }
@@ -507,11 +513,11 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
 
 // weight gradient of conv `ci` from dy (scratch buffer index gi): on the side stream when overlap is on
 // in_bn >= 0: conv_in is the PRE-BN output of the layer with BatchNorm `in_bn`; its BN + ReLU is applied in the loader
-static int wgrad(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const float* conv_in, hipStream_t st, int in_bn = -1) {
+static int wgrad_launch(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const float* conv_in, hipStream_t st, int in_bn,
+                        bool async) {
     Conv& c = n->convs[ci];
     const float* dy = ws + n->scratch[gi];
     hipStream_t ws_st = st;
-    const bool async = n->async_wgrad();
     if (async) {
         if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
         if (hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) return OSI_ERR_LAUNCH;
@@ -533,6 +539,43 @@ static int wgrad(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const
     }
     OSI_TRY(n->mark(OSI_PROF_CONV_WGRAD, ws_st));
     return OSI_OK;
+}
+
+// staggered schedule: issue the weight gradient that was held back, behind everything enqueued on `st` so far
+static int flush_wgrad(osi_resnet50* n, hipStream_t st) {
+    if (!n->pend.on) return OSI_OK;
+    osi_resnet50::PendingW p = n->pend;
+    n->pend.on = false;
+    OSI_TRY(wgrad_launch(n, p.ci, p.grads, p.ws, p.gi, p.conv_in, st, p.in_bn, true));
+    if (hipEventRecord(n->ev_wdone, n->side) != hipSuccess) return OSI_ERR_LAUNCH;
+    n->w_inflight = true;
+    return OSI_OK;
+}
+
+// staggered schedule: an input gradient may only start once the weight gradient issued before it has finished
+static int before_dgrad(osi_resnet50* n, hipStream_t st) {
+    if (!n->w_inflight) return OSI_OK;
+    if (hipStreamWaitEvent(st, n->ev_wdone, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+    n->w_inflight = false;
+    return OSI_OK;
+}
+
+static int wgrad(osi_resnet50* n, int ci, float* grads, float* ws, int gi, const float* conv_in, hipStream_t st, int in_bn = -1) {
+    const bool async = n->async_wgrad();
+    if (!(async && n->stagger)) return wgrad_launch(n, ci, grads, ws, gi, conv_in, st, in_bn, async);
+    OSI_TRY(flush_wgrad(n, st));       // two weight gradients with no input gradient between them: the older one goes now
+    n->pend.on = true; n->pend.ci = ci; n->pend.gi = gi; n->pend.in_bn = in_bn; n->pend.conv_in = conv_in; n->pend.grads = grads; n->pend.ws = ws;
+    // every caller issues the input gradient that flushes this launch BEFORE giving the dy buffer back (the stem, which has no input
+    // gradient, is flushed at the end of the call, before the join), so the buffer's reader event exists by the time it can be taken
+    return OSI_OK;
+}
+
+// plain input gradient (no fused epilogue) with the staggered-schedule hooks
+static int dgrad_plain(osi_resnet50* n, const osi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, hipStream_t st) {
+    OSI_TRY(before_dgrad(n, st));
+    OSI_TRY(osi_conv_dgrad(d, dy, w, dx, accumulate, OSI_TILE_AUTO, st));
+    OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, st));
+    return flush_wgrad(n, st);
 }
 
 // backward of conv+BN(+ReLU mask): dout (in scratch buffer gi) -> dy in place, then wgrad; returns with dy still in the buffer
@@ -580,11 +623,12 @@ static int dgrad_fused(osi_resnet50* n, int ci, const float* params, float* ws, 
     }
     f.partials = ws + n->dg_ws; f.partials_bytes = n->dg_ws_bytes;
     int P = 0;
+    OSI_TRY(before_dgrad(n, st));
     OSI_TRY(osi_conv_dgrad_fused(&c.d, ws + n->scratch[dyi], params + c.w_off, ws + n->scratch[dxi],
                                  addi >= 0 ? ws + n->scratch[addi] : nullptr, &f, OSI_TILE_AUTO, &P, st));
     n->fused_P = P;
     OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, st));
-    return OSI_OK;
+    return flush_wgrad(n, st);
 }
 
 // One bottleneck block of the backward pass. On entry n->cur_grad holds the gradient w.r.t. the block output: raw (stage entry
@@ -607,8 +651,7 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
             OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
             dxbase = n->take(st);
             if (dxbase < 0) return dxbase;
-            OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dxbase), 0, OSI_TILE_AUTO, st));
-            OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, st));
+            OSI_TRY(dgrad_plain(n, &cd.d, S(t1), params + cd.w_off, S(dxbase), 0, st));
             n->give(t1);
         }
         d3 = n->take(st);
@@ -629,8 +672,7 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
                                               n->bn_ws_bytes, st));
             OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
             OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
-            OSI_TRY(osi_conv_dgrad(&cd.d, S(t1), params + cd.w_off, S(dxbase), 0, OSI_TILE_AUTO, st));
-            OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, st));
+            OSI_TRY(dgrad_plain(n, &cd.d, S(t1), params + cd.w_off, S(dxbase), 0, st));
             n->give(t1);
         }
         BN& b3 = n->bns[c3.bn];
@@ -664,8 +706,7 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
         n->cur_grad = dxn;
         n->go_fused = true;
     } else {
-        OSI_TRY(osi_conv_dgrad(&c1.d, S(t3), params + c1.w_off, S(dxbase), 1, OSI_TILE_AUTO, st));
-        OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, st));
+        OSI_TRY(dgrad_plain(n, &c1.d, S(t3), params + c1.w_off, S(dxbase), 1, st));
         n->cur_grad = dxbase;
         n->go_fused = false;
     }
@@ -734,6 +775,8 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
     }
     // Join once per call: every gradient of the stages just run is final on `st` from here on. A data-parallel caller issues
     // one stage per call (and reduces that slice next); a single-GPU caller issues all stages in one call and pays one join.
+    OSI_TRY(flush_wgrad(n, st));
+    n->w_inflight = false;             // the join below covers it
     OSI_TRY(n->join_side(st));
     return OSI_OK;
 }
@@ -748,6 +791,7 @@ int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
     OSI_REQUIRE(n && name);
     if (!strcmp(name, "overlap")) n->overlap = value != 0;
     else if (!strcmp(name, "fwd_fork")) n->fwd_fork = value != 0;
+    else if (!strcmp(name, "stagger")) n->stagger = value != 0;
     else if (!strcmp(name, "fwd_recompute")) n->fwd_recompute = value != 0;
     else if (!strcmp(name, "side_priority_normal")) {
         if (n->side) return OSI_ERR_STATE;   // the side stream already exists with the other priority

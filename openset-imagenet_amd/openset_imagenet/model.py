@@ -46,6 +46,8 @@ class _Net:
             N.check(N.lib().osi_resnet50_set_option(self.h, b"fwd_recompute", 1))
         if os.environ.get("OSI_FWD_FORK") == "0":
             N.check(N.lib().osi_resnet50_set_option(self.h, b"fwd_fork", 0))
+        if os.environ.get("OSI_STAGGER") == "1":   # weight gradients beside the BatchNorm-backward kernels only, never beside an input gradient
+            N.check(N.lib().osi_resnet50_set_option(self.h, b"stagger", 1))
         if os.environ.get("OSI_SIDE_PRIO", "")[:1] == "n":
             N.check(N.lib().osi_resnet50_set_option(self.h, b"side_priority_normal", 1))
 
