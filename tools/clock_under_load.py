@@ -6,8 +6,8 @@ Runs the bench step (Protocol-2 shapes, B = 128, the product path) in a loop for
 `amd-smi metric --clock --power --temperature --json` (falling back to `rocm-smi --showclocks --showpower --json`) every ~0.3 s, and
 once more when the GPU is idle before / after. Prints one JSON line: per-sample shader clocks, socket power, the power cap, and the
 step rate measured over the same interval. It is the out-of-kernel counterpart of the in-kernel clock reads in
-tools/probes/conv_ablate.hip (s_memtime / s_memrealtime): if the chip holds 1.6-1.7 GHz at its power cap under this load, the fp32
-MFMA roofline that binds the conv stack is the one at that clock, not at the 2.4 GHz peak clock.
+tools/probes/conv_ablate.hip (s_memtime / s_memrealtime; its `steady` and `long` modes) and of tools/clock_in_step.sh (GRBM_GUI_ACTIVE):
+all three put the busy training step at ~2.35 GHz, well inside the power cap.
 """
 import json
 import os

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -291,6 +292,7 @@ static float run9(const float* X, const float* W, float* Y, int M, int N, int K,
     return ms / reps;
 }
 
+static int g_warm_launches = 30;   // back-to-back launches in front of the stamped one (`steady` mode: enough for ~0.4 s of load)
 template <int V>
 static double clock_ghz(const float* X, const float* W, float* Y, int M, int N, int K) {
     const int MT = (M + 63) / 64, NT = N / 64;
@@ -298,8 +300,8 @@ static double clock_ghz(const float* X, const float* W, float* Y, int M, int N, 
     const size_t smem = (size_t)128 * LDR * sizeof(float);
     unsigned long long* d;
     hipMalloc(&d, (size_t)grid * 16); hipMemset(d, 0, (size_t)grid * 16);
-    for (int i = 0; i < 30; ++i) hipLaunchKernelGGL((k_gemm<V>), dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT, (unsigned long long*)nullptr);
-    hipLaunchKernelGGL((k_gemm<V>), dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT, d);      // hot: stamped launch after 30 back-to-back ones
+    for (int i = 0; i < g_warm_launches; ++i) hipLaunchKernelGGL((k_gemm<V>), dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL((k_gemm<V>), dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT, d);      // hot: stamped launch after the back-to-back ones
     std::vector<unsigned long long> h((size_t)grid * 2);
     hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
     hipFree(d);
@@ -327,7 +329,73 @@ static float run(const float* X, const float* W, float* Y, int M, int N, int K, 
     return ms / reps;
 }
 
-int main() {
+// `conv_ablate long`: ONE shape sized for dispatches of ~8 ms (M = 401408, N = K = 1024; 842 GFLOP), full loop and mfma-only, each
+// launched 6 times back to back. Run under `rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE`: per MI355X_MICROARCH.md ('DVFS give-back')
+// GRBM_GUI_ACTIVE / 8 / dispatch wall time is the effective shader clock on dispatches this long — an out-of-kernel cross-check of
+// the s_memtime / s_memrealtime clock printed here for the same launches.
+static int long_mode() {
+    const int M = 401408, N = 1024, K = 1024;
+    float *X, *W, *Y;
+    if (hipMalloc(&X, (size_t)M * K * 4) != hipSuccess || hipMalloc(&W, (size_t)N * K * 4) != hipSuccess ||
+        hipMalloc(&Y, (size_t)M * N * 4) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+    {
+        std::vector<float> h((size_t)M * K);
+        unsigned s = 12345u;
+        for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (float)(s >> 8) / 16777216.0f - 0.5f; }
+        hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(W, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+    }
+    const double gflop = 2.0 * M * N * K / 1e9;
+    const float t0 = run<0>(X, W, Y, M, N, K, 6), t5 = run<5>(X, W, Y, M, N, K, 6);
+    printf("long shape M=%d N=%d K=%d (%.0f GFLOP, %d workgroups): full loop %.3f ms = %.1f TFLOP/s | mfma-only %.3f ms = %.1f TFLOP/s\n", M, N, K,
+           gflop, (M + 63) / 64 * (N / 64), t0, gflop / t0, t5, gflop / t5);
+    printf("  in-kernel clock (s_memtime / s_memrealtime, median over workgroups): full loop %.3f GHz | mfma-only %.3f GHz\n",
+           clock_ghz<0>(X, W, Y, M, N, K), clock_ghz<5>(X, W, Y, M, N, K));
+    hipFree(X); hipFree(W); hipFree(Y);
+    return 0;
+}
+
+// `conv_ablate steady`: the ResNet shapes again, but every clock stamp and every timing comes after ~0.4 s of back-to-back launches of
+// the same kernel (the shader clock needs tens of milliseconds of load to settle after an idle gap — see `long` mode's first dispatches).
+static int steady_mode() {
+    struct Shape { int M, N, K; const char* what; };
+    const Shape shapes[] = {{100352, 128, 512, "512->128 1x1 @28 (B=128)"}, {25088, 256, 2304, "256->256 3x3 @14 as GEMM"},
+                            {401408, 256, 64, "64->256 1x1 @56"}, {25088, 1024, 256, "256->1024 1x1 @14"},
+                            {6272, 512, 4608, "512->512 3x3 @7 as GEMM"}, {25088, 256, 1024, "1024->256 1x1 @14"},
+                            {6272, 512, 2048, "2048->512 1x1 @7"}};
+    for (const Shape& s : shapes) {
+        float *X, *W, *Y;
+        hipMalloc(&X, (size_t)s.M * s.K * 4); hipMalloc(&W, (size_t)s.N * s.K * 4); hipMalloc(&Y, (size_t)s.M * s.N * 4);
+        std::vector<float> h((size_t)s.M * s.K);
+        for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+        hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(W, h.data(), (size_t)s.N * s.K * 4, hipMemcpyHostToDevice);
+        const double gflop = 2.0 * s.M * s.N * s.K / 1e9;
+        const float t_cold = run<0>(X, W, Y, s.M, s.N, s.K, 10);
+        const int n = (int)(400.0f / t_cold) + 30;
+        g_warm_launches = n;
+        const double c0 = clock_ghz<0>(X, W, Y, s.M, s.N, s.K);
+        const float t0 = run<0>(X, W, Y, s.M, s.N, s.K, n);          // n launches timed as one block: steady state
+        const double c5 = clock_ghz<5>(X, W, Y, s.M, s.N, s.K);
+        const float t5 = run<5>(X, W, Y, s.M, s.N, s.K, n);
+        printf("%-28s %6.2f WG/CU | after idle: full %.1f TFLOP/s | steady (%d launches): full %.1f TFLOP/s at %.2f GHz = %.0f %% of the pipe rate at that clock"
+               " | mfma-only %.1f TFLOP/s at %.2f GHz = %.0f %%\n", s.what, (s.M + 63) / 64 * (s.N / 64) / 256.0, gflop / t_cold, n, gflop / t0, c0,
+               100.0 * (gflop / t0) / (65.54 * c0), gflop / t5, c5, 100.0 * (gflop / t5) / (65.54 * c5));
+        const float t[9] = {t0, run<1>(X, W, Y, s.M, s.N, s.K, n), run<2>(X, W, Y, s.M, s.N, s.K, n), run<3>(X, W, Y, s.M, s.N, s.K, n),
+                            run<4>(X, W, Y, s.M, s.N, s.K, n), t5, run<6>(X, W, Y, s.M, s.N, s.K, n), run<7>(X, W, Y, s.M, s.N, s.K, n),
+                            run<8>(X, W, Y, s.M, s.N, s.K, n)};
+        printf("    steady TFLOP/s: full %.1f | no-gload %.1f | no-lds-store %.1f | no-barrier %.1f | mfma+ldsread %.1f | mfma-only %.1f | 2-ahead %.1f | "
+               "16x16x4 mfma-only %.1f | 16x16x4 full %.1f | 32x64 tile, 2 waves %.1f | LDS-DMA double buffer %.1f\n", gflop / t[0], gflop / t[1], gflop / t[2],
+               gflop / t[3], gflop / t[4], gflop / t[5], gflop / t[6], gflop / t[7], gflop / t[8], gflop / run9(X, W, Y, s.M, s.N, s.K, n),
+               gflop / run10(X, W, Y, s.M, s.N, s.K, n));
+        hipFree(X); hipFree(W); hipFree(Y);
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "long")) return long_mode();
+    if (argc > 1 && !strcmp(argv[1], "steady")) return steady_mode();
     struct Shape { int M, N, K; const char* what; };
     const Shape shapes[] = {{100352, 128, 512, "512->128 1x1 @28 (B=128)"}, {25088, 256, 2304, "256->256 3x3 @14 as GEMM"},
                             {401408, 256, 64, "64->256 1x1 @56"}, {25088, 1024, 256, "256->1024 1x1 @14"},
