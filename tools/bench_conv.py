@@ -19,8 +19,19 @@ S = lambda: torch.cuda.current_stream().cuda_stream
 dev = torch.device("cuda")
 
 
+STEADY_MS = float(os.environ.get("OSI_STEADY_MS", "0"))   # > 0: time only after this many ms of back-to-back launches of the same call
+# (the shader clock needs ~30 ms of load to settle after an idle gap; without this the table is 10-15 % low)
+
+
 def timeit(fn):
     fn(); torch.cuda.synchronize()
+    if STEADY_MS > 0:
+        import time
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < STEADY_MS:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()      # keeps the queue short; the gap is microseconds, far below the clock's time constant
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(REPS):
