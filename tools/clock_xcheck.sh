@@ -7,6 +7,7 @@ set -e
 OUT=gpurun_out/${1:-clock_xcheck}
 mkdir -p $OUT
 export TMPDIR=/tmp
+mkdir -p build && hipcc -O3 --offload-arch=gfx950 tools/probes/conv_ablate.hip -o build/conv_ablate 2>/dev/null
 ./build/conv_ablate long > $OUT/plain.txt
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc -- ./build/conv_ablate long > $OUT/under_pmc.txt 2> $OUT/pmc.err
 find $OUT/pmc -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $OUT/counters.csv
