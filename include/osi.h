@@ -289,6 +289,21 @@ int osi_resnet50_profile_read(osi_resnet50_t net, double* ms_per_class, int* ops
  * `cap` ops and resets the log. Dev instrumentation (tools/timeline.py): how far the weight gradients trail the critical path. */
 int osi_resnet50_timeline_read(osi_resnet50_t net, double* t_ms, int* cls, int* on_side, int cap, int* count);
 
+
+/* ---- debug: the non-smooth decisions of the latest forward (TEST INFRASTRUCTURE — nothing on the product path calls these) ----
+ * The reference's backward (j.backward(), openset_imagenet/train.py:138) differentiates through 49 ReLUs (torchvision's stem ReLU +
+ * three per Bottleneck) and one max-pool arg-max (model.py:17); a whole-network gradient comparison is only tight when both sides
+ * take the same branch at every one of them. Gate i of osi_resnet50_debug_num_gates() = 1 + 3 x 16, in forward order: 0 = the
+ * stem ReLU as the max-pool output sees it (shape [B][64][Hp][Wp]: the gate of the pooled element, all the backward ever uses),
+ * then per bottleneck the ReLU after bn1, after bn2 and the block-output ReLU. Each is read from what the backward kernels
+ * themselves consume (stored bitmask / the gate recomputed from the pre-BN tensor / the arg-max byte). Output: one byte (0 / 1)
+ * per element in NCHW order [B][C][H][W]; pool_argmax_nchw (gate 0 only, may be NULL): int32 flat index h * Ws + w into the
+ * stem's [Hs][Ws] plane, the convention of torch.nn.functional.max_pool2d(return_indices=True). OSI_ERR_STATE before any forward. */
+int osi_resnet50_debug_num_gates(osi_resnet50_t net);
+int osi_resnet50_debug_gate_shape(osi_resnet50_t net, int i, int* C, int* H, int* W);
+int osi_resnet50_debug_gate(osi_resnet50_t net, void* workspace, int i, unsigned char* gate_nchw, int* pool_argmax_nchw,
+                            osi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,7 @@ struct osi_resnet50 {
     size_t stage_lo[4], stage_hi[4];
     // run state
     bool fwd_done = false;
+    bool any_fwd = false;            // some forward has run on this executor (osi_resnet50_debug_gate refuses to read an empty workspace)
     int next_stage = 0;
     int cur_grad = -1;               // scratch index holding the upstream gradient between stages
     bool go_fused = false;           // cur_grad is already ReLU-masked and its BatchNorm reductions wait in dg_ws
@@ -502,6 +503,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
         return OSI_ERR_LAUNCH;
     if (hipMemcpyAsync(logits, ws + n->logits_ws, (size_t)n->B * n->O * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return OSI_ERR_LAUNCH;
+    n->any_fwd = true;
     if (training) {
         OSI_TRY(osi_i64_add(nbt, (int)n->bns.size(), 1, st));
         n->fwd_done = true;
@@ -778,6 +780,93 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
     OSI_TRY(flush_wgrad(n, st));
     n->w_inflight = false;             // the join below covers it
     OSI_TRY(n->join_side(st));
+    return OSI_OK;
+}
+
+// ---- debug: the non-smooth decisions of the latest forward (tests only; the product path never calls these) -------------------
+// The network's only non-differentiable points are its 49 ReLUs and the max-pool's arg-max. A whole-network gradient check
+// against an fp64 oracle is dominated by the few elements where fp32 rounding flips such a decision (2e-2 relative); with the
+// oracle taking THIS run's decisions the comparison is 400x tighter (tests/test_gate_pinned_gpu.py). Each gate is read from what
+// the backward itself consumes: the stored bitmask for block outputs, fma(y0, scale0, shift0) > 0 for the in-block activations
+// that were never materialised (the expression the forward loader and the dgrad epilogue evaluate), bit 7 / the low bits of the
+// arg-max byte for the fused stem tail. Output order is the oracle's NCHW.
+namespace {
+__global__ __launch_bounds__(256) void k_dbg_gate_bits(const unsigned long long* __restrict__ bits, unsigned char* __restrict__ out,
+                                                       size_t n, int HW, int C) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;   // NHWC element index
+    if (e >= n) return;
+    const size_t i4 = e >> 2;
+    const unsigned long long w = bits[(i4 >> 6) * 4 + (e & 3)];
+    const size_t pix = e / C;
+    const int c = (int)(e - pix * C);
+    const size_t b = pix / HW, hw = pix - b * HW;
+    out[(b * C + c) * HW + hw] = (unsigned char)((w >> (i4 & 63)) & 1);
+}
+__global__ __launch_bounds__(256) void k_dbg_gate_fma(const float* __restrict__ y, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, unsigned char* __restrict__ out, size_t n, int HW,
+                                                      int C) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const size_t pix = e / C;
+    const int c = (int)(e - pix * C);
+    const size_t b = pix / HW, hw = pix - b * HW;
+    out[(b * C + c) * HW + hw] = __builtin_fmaf(y[e], scale[c], shift[c]) > 0.f ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_dbg_gate_pool(const uint32_t* __restrict__ idx, unsigned char* __restrict__ gate,
+                                                       int* __restrict__ argmax, size_t n, int Ws, int Hp, int Wp, int C) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;   // NHWC element of the pooled tensor
+    if (e >= n) return;
+    const uint32_t byte = (idx[e >> 2] >> (8 * (e & 3))) & 0xffu;
+    const size_t pix = e / C;
+    const int c = (int)(e - pix * C);
+    const size_t b = pix / ((size_t)Hp * Wp), hw = pix - b * Hp * Wp;
+    const int ho = (int)(hw / Wp), wo = (int)(hw - (size_t)ho * Wp);
+    const int tap = byte & 0x7f, r = tap / 3, s = tap - 3 * r;
+    const size_t o = (b * C + c) * ((size_t)Hp * Wp) + hw;
+    gate[o] = (unsigned char)(byte >> 7);
+    if (argmax) argmax[o] = (ho * 2 - 1 + r) * Ws + (wo * 2 - 1 + s);
+}
+}  // namespace
+
+int osi_resnet50_debug_num_gates(osi_resnet50_t n) { return n ? 1 + 3 * (int)n->blocks.size() : 0; }
+
+int osi_resnet50_debug_gate_shape(osi_resnet50_t n, int i, int* C, int* H, int* W) {
+    OSI_REQUIRE(n && C && H && W && i >= 0 && i < 1 + 3 * (int)n->blocks.size());
+    if (i == 0) { *C = 64; *H = n->Hp; *W = n->Wp; return OSI_OK; }
+    const Block& k = n->blocks[(i - 1) / 3];
+    const int which = (i - 1) % 3;
+    const osi_conv_desc& d = n->convs[which == 0 ? k.c1 : which == 1 ? k.c2 : k.c3].d;
+    *C = d.Cout; *H = d.Ho; *W = d.Wo;
+    return OSI_OK;
+}
+
+int osi_resnet50_debug_gate(osi_resnet50_t n, void* workspace, int i, unsigned char* gate_nchw, int* pool_argmax_nchw,
+                            osi_stream_t stream) {
+    OSI_REQUIRE(n && workspace && gate_nchw && i >= 0 && i < 1 + 3 * (int)n->blocks.size());
+    OSI_REQUIRE(i == 0 || !pool_argmax_nchw);
+    if (!n->any_fwd) return OSI_ERR_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    if (i == 0) {
+        const size_t e = (size_t)n->B * n->Hp * n->Wp * 64;
+        hipLaunchKernelGGL(k_dbg_gate_pool, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, (const uint32_t*)(ws + n->pool_idx),
+                           gate_nchw, pool_argmax_nchw, e, n->Ws, n->Hp, n->Wp, 64);
+        OSI_LAUNCH_CHECK();
+        return OSI_OK;
+    }
+    const Block& k = n->blocks[(i - 1) / 3];
+    const int which = (i - 1) % 3;
+    const Conv& c = n->convs[which == 0 ? k.c1 : which == 1 ? k.c2 : k.c3];
+    const BN& b = n->bns[c.bn];
+    const size_t e = (size_t)b.M * b.C;
+    const int HW = c.d.Ho * c.d.Wo;
+    if (which == 2)
+        hipLaunchKernelGGL(k_dbg_gate_bits, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st,
+                           (const unsigned long long*)(ws + c.mask), gate_nchw, e, HW, b.C);
+    else
+        hipLaunchKernelGGL(k_dbg_gate_fma, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, ws + c.y, ws + b.scale, ws + b.shift,
+                           gate_nchw, e, HW, b.C);
+    OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
 

@@ -104,6 +104,9 @@ _SIGS = {
     "osi_resnet50_profile": (c_int, [c_void_p, c_int]),
     "osi_resnet50_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int)]),
     "osi_resnet50_timeline_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int), POINTER(c_int), c_int, POINTER(c_int)]),
+    "osi_resnet50_debug_num_gates": (c_int, [c_void_p]),
+    "osi_resnet50_debug_gate_shape": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "osi_resnet50_debug_gate": (c_int, [c_void_p, P, c_int, P, P, P]),
     "osi_resnet50_forward": (c_int, [c_void_p, P, P, P, P, P, P, P, c_int, P]),
     "osi_resnet50_backward": (c_int, [c_void_p, P, P, P, P, P, c_int, c_int, P]),
 }

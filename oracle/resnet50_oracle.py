@@ -106,29 +106,59 @@ def _bn(sd, prefix, x, training):
     return F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"], training, 0.1, 1e-5)
 
 
-def forward(sd, image, training=True, taps=None):
-    """(logits, features) of the reference model for NCHW `image`. `taps` (dict) optionally receives intermediate tensors."""
+def forward(sd, image, training=True, taps=None, gates=None, record_gates=None):
+    """(logits, features) of the reference model for NCHW `image`. `taps` (dict) optionally receives intermediate tensors.
+
+    Gate pinning (test infrastructure for the whole-network backward check): the network's only non-smooth operations are its
+    49 ReLUs and the max-pool's arg-max, and two correct implementations that differ by fp32 rounding take different branches
+    wherever a pre-activation is within rounding of zero — an O(1) change per flipped element that dominates any gradient
+    comparison (2e-2 relative). `record_gates` (dict) receives the decisions this run took:
+        "relu": list of 49 bool tensors in forward order (stem — taken AFTER the max-pool, i.e. the gate of the pooled value, which
+                is all the backward ever sees of the stem ReLU — then bn1 / bn2 / block output of each of the 16 bottlenecks),
+        "pool_idx": int64 [B, 64, Hp, Wp] flat arg-max index into the H*W plane (torch.nn.functional.max_pool2d's convention).
+    `gates` (same structure) makes the run TAKE the given decisions instead of its own: relu(x) becomes x * gate and the max-pool
+    a gather — identical values wherever the decisions agree, and a gradient that is a smooth function of the inputs.
+    """
     def tap(k, v):
         if taps is not None:
             taps[k] = v
         return v
 
+    n_relu = [0]
+
+    def relu(v):
+        i = n_relu[0]
+        n_relu[0] += 1
+        if record_gates is not None:
+            record_gates.setdefault("relu", []).append((v > 0).detach())
+        if gates is None:
+            return F.relu(v)
+        return v * gates["relu"][i].to(v.dtype)
+
     x = F.conv2d(image, sd["resnet_base.conv1.weight"], None, 2, 3)
     tap("conv1", x)
-    x = F.relu(_bn(sd, "resnet_base.bn1", x, training))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _bn(sd, "resnet_base.bn1", x, training)
+    # relu then max-pool == max-pool then relu (monotone), and only the pooled element's gate ever reaches the backward
+    if gates is None:
+        x, idx = F.max_pool2d(x, 3, 2, 1, return_indices=True)
+    else:
+        idx = gates["pool_idx"]
+        x = torch.gather(x.flatten(2), 2, idx.flatten(2)).view(idx.shape)
+    if record_gates is not None:
+        record_gates["pool_idx"] = idx.detach()
+    x = relu(x)
     tap("maxpool", x)
     for s, (planes, blocks, stride) in enumerate(STAGES):
         for b in range(blocks):
             pre = f"resnet_base.layer{s + 1}.{b}."
             st = stride if b == 0 else 1
             identity = x
-            out = F.relu(_bn(sd, pre + "bn1", F.conv2d(x, sd[pre + "conv1.weight"]), training))
-            out = F.relu(_bn(sd, pre + "bn2", F.conv2d(out, sd[pre + "conv2.weight"], None, st, 1), training))
+            out = relu(_bn(sd, pre + "bn1", F.conv2d(x, sd[pre + "conv1.weight"]), training))
+            out = relu(_bn(sd, pre + "bn2", F.conv2d(out, sd[pre + "conv2.weight"], None, st, 1), training))
             out = _bn(sd, pre + "bn3", F.conv2d(out, sd[pre + "conv3.weight"]), training)
             if b == 0:
                 identity = _bn(sd, pre + "downsample.1", F.conv2d(x, sd[pre + "downsample.0.weight"], None, st), training)
-            x = F.relu(out + identity)
+            x = relu(out + identity)
             tap(f"layer{s + 1}.{b}", x)
     x = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
     tap("pooled", x)
@@ -137,16 +167,27 @@ def forward(sd, image, training=True, taps=None):
     return logits, features
 
 
+def gate_disagreements(a, b):
+    """(differing ReLU decisions, differing arg-max positions, total ReLU decisions) between two gate records. An arg-max only
+    counts where the pooled element's gate is open on either side: behind a closed gate no gradient flows, and an implementation
+    that pools AFTER the ReLU (all-zero window: first element wins) legitimately names another element than one that pools before."""
+    d = sum(int((x != y).sum()) for x, y in zip(a["relu"], b["relu"]))
+    n = sum(x.numel() for x in a["relu"])
+    live = a["relu"][0] | b["relu"][0]
+    return d, int(((a["pool_idx"] != b["pool_idx"]) & live).sum()), n
+
+
 def param_keys(sd):
     return [k for k in sd if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
 
 
-def forward_backward(sd, image, target, loss_fn, training=True):
-    """One forward + loss + backward. Returns (logits, features, loss, {param key: grad}); running stats in `sd` are updated."""
+def forward_backward(sd, image, target, loss_fn, training=True, gates=None, record_gates=None):
+    """One forward + loss + backward. Returns (logits, features, loss, {param key: grad}); running stats in `sd` are updated.
+    `gates` / `record_gates`: see forward()."""
     leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in param_keys(sd)}
     work = dict(sd)
     work.update(leaves)
-    logits, features = forward(work, image, training)
+    logits, features = forward(work, image, training, gates=gates, record_gates=record_gates)
     for k in sd:  # carry the in-place buffer updates back
         if k.endswith("num_batches_tracked"):
             sd[k] = work[k]

@@ -56,3 +56,23 @@ def conv_wgrad(dy_nhwc, x_nhwc, k, stride, pad):
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x_nhwc.device)
     N.check(N.lib().osi_conv_wgrad(ctypes.byref(d), N.ptr(dy_nhwc), N.ptr(x_nhwc), N.ptr(dw), N.ptr(ws), nbytes, S()), "conv_wgrad")
     return dw if stem else dw.view(Cout, k, k, Cin)
+
+
+def hip_gates(model):
+    """The ReLU / arg-max decisions of the model's latest forward, in the structure oracle.resnet50_oracle.forward(gates=...)
+    takes: {"relu": [49 bool tensors, NCHW], "pool_idx": int64 [B,64,Hp,Wp]} (CPU tensors). Read through the debug entry points of
+    the C ABI (include/osi.h, "debug" section), i.e. from the very buffers the backward kernels consume."""
+    net, _ = model._last
+    lib, dev = N.lib(), model._flat_params.device
+    B = next(b for (b, h, w), n in model._nets.items() if n is net)
+    relu, pool_idx = [], None
+    C, H, W = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    for i in range(lib.osi_resnet50_debug_num_gates(net.h)):
+        N.check(lib.osi_resnet50_debug_gate_shape(net.h, i, ctypes.byref(C), ctypes.byref(H), ctypes.byref(W)))
+        g = torch.empty(B, C.value, H.value, W.value, dtype=torch.uint8, device=dev)
+        am = torch.empty(B, C.value, H.value, W.value, dtype=torch.int32, device=dev) if i == 0 else None
+        N.check(lib.osi_resnet50_debug_gate(net.h, N.ptr(model._ws), i, N.ptr(g), N.ptr(am), S()), "debug_gate")
+        relu.append(g.cpu().bool())
+        if am is not None:
+            pool_idx = am.cpu().long()
+    return {"relu": relu, "pool_idx": pool_idx}
