@@ -162,10 +162,10 @@ int osi_u8hwc3_to_nhwc4(const unsigned char* x_u8_nhwc, const unsigned char* fli
                         osi_stream_t stream);
 /* The device side of the reference's input transform Compose([Resize(256), RandomCrop(224) | CenterCrop(224), RandomHorizontalFlip,
  * ToTensor]) (train.py:259-268) after decode + resize: canvas = uint8 [B][Hc][Wc][3] holding the resized image (or a window of it
- * that contains the crop), crop_xy = int32 [B][2] top-left corner (x0, y0) of the HxW crop inside the canvas (NULL = (0, 0); values
- * are clamped on the device into the valid range, in place), flip[b] != 0 mirrors the CROPPED image (NULL = none);
+ * that contains the crop), crop_xy = int32 [B][2] top-left corner (x0, y0) of the HxW crop inside the canvas (NULL = (0, 0); read-only:
+ * the kernel clamps each corner into the valid range in registers), flip[b] != 0 mirrors the CROPPED image (NULL = none);
  * y = fp32 [B][H][W][4], value / 255, 4th channel zero. */
-int osi_u8_crop_flip_to_nhwc4(const unsigned char* canvas_u8, int* crop_xy, const unsigned char* flip, float* y_nhwc4, int B, int Hc,
+int osi_u8_crop_flip_to_nhwc4(const unsigned char* canvas_u8, const int* crop_xy, const unsigned char* flip, float* y_nhwc4, int B, int Hc,
                               int Wc, int H, int W, osi_stream_t stream);
 /* idx: B*Ho*Wo*C bytes (argmax position 0..8 per element) */
 int osi_maxpool3x3s2_fwd(const float* x, float* y, void* idx, int B, int H, int W, int C, osi_stream_t stream);
@@ -250,6 +250,8 @@ int osi_resnet50_bn_info(osi_resnet50_t net, int j, char* prefix, int cap, int* 
 size_t osi_resnet50_buffer_floats(osi_resnet50_t net);
 size_t osi_resnet50_workspace_bytes(osi_resnet50_t net);
 int osi_resnet50_num_stages(osi_resnet50_t net);              /* backward stages (gradient buckets), head first */
+/* the fixed geometry the executor was created for: batch, image height, image width (any pointer may be NULL) */
+int osi_resnet50_geometry(osi_resnet50_t net, int* B, int* H, int* W);
 /* floats [lo, hi) of the grads arena that are final once backward stage s has run */
 int osi_resnet50_stage_grad_range(osi_resnet50_t net, int s, size_t* lo, size_t* hi);
 

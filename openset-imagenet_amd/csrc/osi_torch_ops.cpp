@@ -32,13 +32,17 @@ void ok(int code, const char* what) {
     TORCH_CHECK(code == OSI_OK, "libosi_hip ", what, " failed: ", osi_strerror(code), " (code ", code, ")");
 }
 
-void need(const Tensor& t, at::ScalarType dt, const char* name) {
+// align = 16 for the tensors the kernels read with 16-byte vector accesses (the arenas, images, the workspace); the small per-row
+// tensors (logits, targets, features, class weights, gradients of the head) are read element-wise and only need their natural
+// alignment, so a contiguous row slice such as logits[3:] with an odd class count is accepted
+void need(const Tensor& t, at::ScalarType dt, const char* name, uintptr_t align = 16) {
     TORCH_CHECK(t.defined(), name, ": undefined tensor");
     TORCH_CHECK(t.is_cuda(), "osi::", name, " must live on the GPU: the MI355X build has no CPU path");
     TORCH_CHECK(t.scalar_type() == dt, "osi::", name, " has dtype ", t.scalar_type(), ", expected ", dt);
     TORCH_CHECK(t.is_contiguous(), "osi::", name, " must be contiguous");
-    TORCH_CHECK((reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0, "osi::", name, " must be 16-byte aligned");
+    TORCH_CHECK((reinterpret_cast<uintptr_t>(t.data_ptr()) & (align - 1)) == 0, "osi::", name, " must be ", align, "-byte aligned");
 }
+constexpr uintptr_t NATURAL = 4;   // element-wise readers: fp32 / int64 / fp64 tensors from the allocator or row slices of them
 
 osi_stream_t stream_of(const Tensor& t) {
     return (osi_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
@@ -66,6 +70,14 @@ std::tuple<Tensor, Tensor> resnet50_forward(int64_t net, const Tensor& params, T
     TORCH_CHECK(nbt.numel() == osi_resnet50_num_bn(h), "osi::resnet50_forward: num_batches_tracked size mismatch");
     osi_stream_t st = stream_of(params);
     const int64_t B = image.size(0);
+    {   // the executor was created for ONE geometry: a batch of another shape would read / write outside its workspace
+        int eb = 0, eh = 0, ew = 0;
+        ok(osi_resnet50_geometry(h, &eb, &eh, &ew), "osi_resnet50_geometry");
+        const bool chw = image.scalar_type() != at::kByte && !(image.size(3) == 4 && image.size(1) != 3);
+        const int64_t ih = chw ? image.size(2) : image.size(1), iw = chw ? image.size(3) : image.size(2);
+        TORCH_CHECK(B == eb && ih == eh && iw == ew, "osi::resnet50_forward: image batch ", B, "x", ih, "x", iw,
+                    " does not match the executor's geometry ", eb, "x", eh, "x", ew);
+    }
     const float* img = nullptr;
     if (image.scalar_type() == at::kByte) {
         need(image, at::kByte, "image"); TORCH_CHECK(image.size(3) == 3, "uint8 image batch must be [B,H,W,3]");
@@ -90,8 +102,8 @@ std::tuple<Tensor, Tensor> resnet50_forward(int64_t net, const Tensor& params, T
 void resnet50_backward(int64_t net, const Tensor& params, Tensor grads, Tensor workspace, const Tensor& dlogits,
                        const std::optional<Tensor>& dfeatures, int64_t stage_lo, int64_t stage_hi) {
     need(params, at::kFloat, "params"); need(grads, at::kFloat, "grads"); need(workspace, at::kByte, "workspace");
-    need(dlogits, at::kFloat, "dlogits");
-    if (dfeatures.has_value() && dfeatures->defined()) need(*dfeatures, at::kFloat, "dfeatures");
+    need(dlogits, at::kFloat, "dlogits", NATURAL);
+    if (dfeatures.has_value() && dfeatures->defined()) need(*dfeatures, at::kFloat, "dfeatures", NATURAL);
     TORCH_CHECK(grads.numel() == params.numel(), "osi::resnet50_backward: gradient arena size mismatch");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(params.device());
     ok(osi_resnet50_backward(handle(net), params.data_ptr<float>(), grads.data_ptr<float>(), workspace.data_ptr(),
@@ -103,7 +115,7 @@ void resnet50_backward(int64_t net, const Tensor& params, Tensor grads, Tensor w
 std::tuple<Tensor, Tensor, Tensor> loss_fwd_bwd(int64_t mode, const Tensor& logits, const Tensor& target, double unk_weight,
                                                 int64_t ignore_index, const std::optional<Tensor>& class_weights,
                                                 const std::optional<Tensor>& features, double xi, double alpha, bool need_grad) {
-    need(logits, at::kFloat, "logits"); need(target, at::kLong, "target");
+    need(logits, at::kFloat, "logits", NATURAL); need(target, at::kLong, "target", NATURAL);
     TORCH_CHECK(logits.dim() == 2 && target.dim() == 1 && target.size(0) == logits.size(0), "expected logits [B, C] and target [B]");
     const int B = (int)logits.size(0), C = (int)logits.size(1);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(logits.device());
@@ -111,9 +123,9 @@ std::tuple<Tensor, Tensor, Tensor> loss_fwd_bwd(int64_t mode, const Tensor& logi
     Tensor dlogits = need_grad ? at::empty_like(logits) : at::empty({0}, logits.options());
     Tensor dfeat = at::empty({0}, logits.options());
     int F = 0;
-    if (class_weights.has_value() && class_weights->defined()) { need(*class_weights, at::kFloat, "class_weights"); TORCH_CHECK(class_weights->numel() == C); }
+    if (class_weights.has_value() && class_weights->defined()) { need(*class_weights, at::kFloat, "class_weights", NATURAL); TORCH_CHECK(class_weights->numel() == C); }
     if (features.has_value() && features->defined()) {
-        need(*features, at::kFloat, "features"); TORCH_CHECK(features->dim() == 2 && features->size(0) == B);
+        need(*features, at::kFloat, "features", NATURAL); TORCH_CHECK(features->dim() == 2 && features->size(0) == B);
         F = (int)features->size(1);
         dfeat = at::empty_like(*features);
     }
@@ -145,9 +157,9 @@ Tensor stage_canvas(const Tensor& canvas, const std::optional<Tensor>& crop_xy, 
     need(canvas, at::kByte, "canvas");
     TORCH_CHECK(canvas.dim() == 4 && canvas.size(3) == 3, "canvas must be uint8 [B,Hc,Wc,3]");
     const int B = (int)canvas.size(0);
-    int* cp = nullptr; const unsigned char* fl = nullptr;
-    if (crop_xy.has_value() && crop_xy->defined()) { need(*crop_xy, at::kInt, "crop_xy"); TORCH_CHECK(crop_xy->numel() == 2 * B); cp = crop_xy->data_ptr<int>(); }
-    if (flip.has_value() && flip->defined()) { need(*flip, at::kByte, "flip"); TORCH_CHECK(flip->numel() == B); fl = flip->data_ptr<unsigned char>(); }
+    const int* cp = nullptr; const unsigned char* fl = nullptr;
+    if (crop_xy.has_value() && crop_xy->defined()) { need(*crop_xy, at::kInt, "crop_xy", NATURAL); TORCH_CHECK(crop_xy->numel() == 2 * B); cp = crop_xy->data_ptr<int>(); }
+    if (flip.has_value() && flip->defined()) { need(*flip, at::kByte, "flip", 1); TORCH_CHECK(flip->numel() == B); fl = flip->data_ptr<unsigned char>(); }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(canvas.device());
     Tensor out = at::empty({B, H, W, 4}, canvas.options().dtype(at::kFloat));
     ok(osi_u8_crop_flip_to_nhwc4(canvas.data_ptr<unsigned char>(), cp, fl, out.data_ptr<float>(), B, (int)canvas.size(1), (int)canvas.size(2),
@@ -156,7 +168,7 @@ Tensor stage_canvas(const Tensor& canvas, const std::optional<Tensor>& crop_xy, 
 }
 
 Tensor softmax(const Tensor& logits) {
-    need(logits, at::kFloat, "logits"); TORCH_CHECK(logits.dim() == 2);
+    need(logits, at::kFloat, "logits", NATURAL); TORCH_CHECK(logits.dim() == 2);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(logits.device());
     Tensor out = at::empty_like(logits);
     ok(osi_softmax(logits.data_ptr<float>(), out.data_ptr<float>(), (int)logits.size(0), (int)logits.size(1), stream_of(logits)), "osi_softmax");
@@ -165,7 +177,7 @@ Tensor softmax(const Tensor& logits) {
 
 void confidence_accumulate(const Tensor& logits, const Tensor& target, double offset, int64_t unknown_class, int64_t last_valid_class,
                            Tensor acc4) {
-    need(logits, at::kFloat, "logits"); need(target, at::kLong, "target"); need(acc4, at::kDouble, "acc4");
+    need(logits, at::kFloat, "logits", NATURAL); need(target, at::kLong, "target", NATURAL); need(acc4, at::kDouble, "acc4", NATURAL);
     TORCH_CHECK(logits.dim() == 2 && target.numel() == logits.size(0) && acc4.numel() == 4);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(logits.device());
     ok(osi_confidence_accumulate(logits.data_ptr<float>(), (const long long*)target.data_ptr<int64_t>(), (int)logits.size(0),
@@ -185,7 +197,7 @@ TORCH_LIBRARY(osi, m) {
     m.def("adam_step(Tensor(a!) params, Tensor grads, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, float beta2, "
           "float eps, int step, float grad_scale) -> ()");
     m.def("sgd_step(Tensor(a!) params, Tensor grads, Tensor(b!) momentum_buffer, float lr, float momentum, bool first, float grad_scale) -> ()");
-    m.def("stage_canvas(Tensor canvas, Tensor(a!)? crop_xy, Tensor? flip, int H, int W) -> Tensor");   // crop corners are clamped in place
+    m.def("stage_canvas(Tensor canvas, Tensor? crop_xy, Tensor? flip, int H, int W) -> Tensor");   // crop corners are read-only (clamped in registers)
     m.def("softmax(Tensor logits) -> Tensor");
     m.def("confidence_accumulate(Tensor logits, Tensor target, float offset, int unknown_class, int last_valid_class, Tensor(a!) acc4) -> ()");
 }

@@ -168,36 +168,25 @@ __global__ __launch_bounds__(256) void k_u8_crop_flip_to_nhwc4(const unsigned ch
         const int w = (int)(i - row * W);
         const int b = (int)(row / H);
         const int h = (int)(row - (size_t)b * H);
-        const int x0 = crop ? crop[2 * b] : 0, y0 = crop ? crop[2 * b + 1] : 0;
+        // corners arrive from the host loader: clamped HERE, in registers, into [0, Wc - W] x [0, Hc - H] so that a bad offset can
+        // never read outside the canvas; the caller's tensor is read-only
+        const int x0 = crop ? min(max(crop[2 * b], 0), Wc - W) : 0, y0 = crop ? min(max(crop[2 * b + 1], 0), Hc - H) : 0;
         const int ws = x0 + ((flip && flip[b]) ? W - 1 - w : w);
         const unsigned char* s = x + (((size_t)b * Hc + (y0 + h)) * Wc + ws) * 3;
         y[i] = f32x4{(float)s[0] / 255.0f, (float)s[1] / 255.0f, (float)s[2] / 255.0f, 0.f};
     }
 }
-// Crop corners arrive from the host loader; they are clamped on the device into [0, Wc - W] x [0, Hc - H] before the copy so that a
-// bad offset can never read outside the canvas (no host sync, one thread per image).
-__global__ void k_clamp_crop(int* crop, int B, int maxx, int maxy) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    crop[2 * b] = min(max(crop[2 * b], 0), maxx);
-    crop[2 * b + 1] = min(max(crop[2 * b + 1], 0), maxy);
-}
-
 }  // namespace
 
 extern "C" {
 
-int osi_u8_crop_flip_to_nhwc4(const unsigned char* canvas, int* crop_xy, const unsigned char* flip, float* y, int B, int Hc, int Wc,
+int osi_u8_crop_flip_to_nhwc4(const unsigned char* canvas, const int* crop_xy, const unsigned char* flip, float* y, int B, int Hc, int Wc,
                               int H, int W, osi_stream_t stream) {
     OSI_REQUIRE(canvas && y && B > 0 && H > 0 && W > 0 && Hc >= H && Wc >= W);
     hipStream_t st = (hipStream_t)stream;
-    if (crop_xy) {   // an out-of-range corner would read outside the canvas: clamp on the device (no host sync)
-        hipLaunchKernelGGL(k_clamp_crop, dim3((B + 63) / 64), dim3(64), 0, st, crop_xy, B, Wc - W, Hc - H);
-        OSI_LAUNCH_CHECK();
-    }
     size_t n = (size_t)B * H * W;
     int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_u8_crop_flip_to_nhwc4, dim3(grid), dim3(256), 0, st, canvas, (const int*)crop_xy, flip, (f32x4*)y, B, Hc, Wc, H, W);
+    hipLaunchKernelGGL(k_u8_crop_flip_to_nhwc4, dim3(grid), dim3(256), 0, st, canvas, crop_xy, flip, (f32x4*)y, B, Hc, Wc, H, W);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }

@@ -293,6 +293,13 @@ int osi_resnet50_num_bn(osi_resnet50_t net) { return net ? (int)net->bns.size() 
 size_t osi_resnet50_buffer_floats(osi_resnet50_t net) { return net ? net->buffer_floats : 0; }
 size_t osi_resnet50_workspace_bytes(osi_resnet50_t net) { return net ? net->ws_floats * sizeof(float) : 0; }
 int osi_resnet50_num_stages(osi_resnet50_t net) { return net ? net->n_stages : 0; }
+int osi_resnet50_geometry(osi_resnet50_t net, int* B, int* H, int* W) {
+    OSI_REQUIRE(net);
+    if (B) *B = net->B;
+    if (H) *H = net->H;
+    if (W) *W = net->W;
+    return OSI_OK;
+}
 
 int osi_resnet50_tensor_info(osi_resnet50_t net, int i, char* name, int name_cap, int* ndim, int* shape, size_t* offset,
                              size_t* numel) {

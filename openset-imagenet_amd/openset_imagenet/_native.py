@@ -98,6 +98,7 @@ _SIGS = {
     "osi_resnet50_buffer_floats": (c_size_t, [c_void_p]),
     "osi_resnet50_workspace_bytes": (c_size_t, [c_void_p]),
     "osi_resnet50_num_stages": (c_int, [c_void_p]),
+    "osi_resnet50_geometry": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "osi_resnet50_stage_grad_range": (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     "osi_resnet50_set_overlap": (c_int, [c_void_p, c_int]),
     "osi_resnet50_set_option": (c_int, [c_void_p, c_char_p, c_int]),

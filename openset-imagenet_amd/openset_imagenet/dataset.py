@@ -44,6 +44,57 @@ class LabelTable:
         return torch.from_numpy(len(self.labels) / (counts * self.label_count)).float()
 
 
+class ImagenetDataset(torch.utils.data.Dataset):
+    """The reference's dataset class with its own constructor and members (reference dataset.py:10-86):
+    `ImagenetDataset(csv_file, imagenet_path, transform=None)`, samples `(image, label)` with `transform` applied to the decoded
+    RGB PIL image, attributes `dataset` (the CSV frame), `imagenet_path`, `transform`, `label_count`, `unique_classes`, and the
+    label rewrites `has_negatives / replace_negative_label / remove_negative_label / calculate_class_weights`.
+
+    This is the compatibility surface for reference-style callers; worker() itself feeds the GPU through pipeline.CanvasDataset
+    (uint8 canvases, crop / flip / ToTensor on the device). Both share LabelTable, so the label arithmetic is one implementation."""
+
+    def __init__(self, csv_file, imagenet_path, transform=None):
+        import pathlib
+        import pandas as pd
+        self.dataset = pd.read_csv(csv_file, header=None)
+        self.imagenet_path = pathlib.Path(imagenet_path)
+        self.transform = transform
+        self._sync(LabelTable(self.dataset[1].to_numpy()))
+
+    def _sync(self, table):
+        self._table = table
+        self.label_count, self.unique_classes = table.label_count, table.unique_classes
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, index):
+        from PIL import Image
+        if torch.is_tensor(index):
+            index = index.tolist()
+        rel_path, label = self.dataset.iloc[index]
+        image = Image.open(self.imagenet_path / rel_path).convert("RGB")
+        if self.transform is not None:
+            image = self.transform(image)
+        return image, torch.as_tensor(int(label), dtype=torch.int64)
+
+    def has_negatives(self):
+        return self._table.has_negatives()
+
+    def replace_negative_label(self):
+        self._table.replace_negative_label()
+        self.dataset[1] = self._table.labels
+        self._sync(self._table)
+
+    def remove_negative_label(self):
+        self.dataset = self.dataset[self.dataset[1] >= 0].reset_index(drop=True)
+        self._table.remove_negative_label()
+        self._sync(self._table)
+
+    def calculate_class_weights(self):
+        return self._table.calculate_class_weights()
+
+
 class SyntheticImagenet(torch.utils.data.Dataset):
     """Deterministic stand-in for ImagenetDataset: fp32 images in [0,1) of shape [3,224,224] (ToTensor() without mean/std
     normalisation, reference train.py:259-263) and int64 labels drawn from a given label table."""

@@ -37,7 +37,34 @@ def _launch_ranks(config, argv):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(config.dist.port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-m", "openset_imagenet.script.train", *argv], env=env))
-    codes = [p.wait() for p in procs]
+    return _wait_ranks(procs)
+
+
+def _wait_ranks(procs, poll_seconds=0.2, grace_seconds=10.0):
+    """Poll the child ranks; on the first non-zero exit terminate the survivors (they would otherwise sit in an RCCL collective
+    until the process-group timeout) and report every exit code."""
+    import time
+    codes = [None] * len(procs)
+    failed = False
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if not failed and any(c not in (None, 0) for c in codes):
+            failed = True
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()                     # the exact children this function was given, never a pattern
+            deadline = time.time() + grace_seconds
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=max(0.0, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+        if any(c is None for c in codes):
+            time.sleep(poll_seconds)
     if any(codes):
         raise SystemExit(f"data-parallel ranks exited with {codes}")
     return 0

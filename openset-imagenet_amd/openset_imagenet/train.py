@@ -326,28 +326,42 @@ def _worker_body(cfg, log, out_dir, rank, world, distributed):
             sampler.set_epoch(epoch)
         train(net, train_loader, opt, loss_fn, t_metrics, cfg)
         t1 = time.time()
-        stop = False
+        stop, failure = False, None
         if rank == 0:                                     # validate / log / checkpoint on the first process only
-            validate(model, val_loader, loss_fn, n_classes, v_metrics, cfg)
-            curr_score = v_metrics["conf_kn"].avg + v_metrics["conf_unk"].avg
-            scalars.write(f"{epoch},{t_metrics['j'].avg},{v_metrics['j'].avg},{v_metrics['conf_kn'].avg},{v_metrics['conf_unk'].avg}\n")
-            scalars.flush()
-            log.info(f"ep:{epoch} train:{t_metrics} val:{v_metrics} t:{t1 - t0:.1f}s v:{time.time() - t1:.1f}s")
-            save_checkpoint(out_dir / (cfg.name + "_curr.pth"), model, epoch, opt, curr_score, scheduler)
-            _last_worker_state["checkpoints_written"] += 1
-            if curr_score > best_score:
-                best_score = curr_score
-                save_checkpoint(out_dir / (cfg.name + "_best.pth"), model, epoch, opt, best_score, scheduler)
-                _last_worker_state["checkpoints_written"] += 1
-            if early is not None:
-                early(metrics=curr_score, loss=False)
-                stop = early.early_stop
-        if scheduler is not None:
+            try:
+                validate(model, val_loader, loss_fn, n_classes, v_metrics, cfg)
+                curr_score = v_metrics["conf_kn"].avg + v_metrics["conf_unk"].avg
+            except BaseException as e:                    # the other ranks wait in the broadcast below: tell them before re-raising
+                failure = e
+        # learning-rate schedule: stepped on every rank, after validation and BEFORE the checkpoints are written (reference
+        # train.py:435-437 then :463-471), so that `_curr.pth` / `_best.pth` carry the scheduler state and learning rate of the epoch
+        # they resume into
+        if scheduler is not None and failure is None:
             scheduler.step()
-        if distributed:                                   # every rank follows rank 0's early-stopping decision
-            flag = [stop, best_score]
+        if rank == 0 and failure is None:
+            try:
+                scalars.write(f"{epoch},{t_metrics['j'].avg},{v_metrics['j'].avg},{v_metrics['conf_kn'].avg},{v_metrics['conf_unk'].avg}\n")
+                scalars.flush()
+                log.info(f"ep:{epoch} train:{t_metrics} val:{v_metrics} t:{t1 - t0:.1f}s v:{time.time() - t1:.1f}s")
+                save_checkpoint(out_dir / (cfg.name + "_curr.pth"), model, epoch, opt, curr_score, scheduler)
+                _last_worker_state["checkpoints_written"] += 1
+                if curr_score > best_score:
+                    best_score = curr_score
+                    save_checkpoint(out_dir / (cfg.name + "_best.pth"), model, epoch, opt, best_score, scheduler)
+                    _last_worker_state["checkpoints_written"] += 1
+                if early is not None:
+                    early(metrics=curr_score, loss=False)
+                    stop = early.early_stop
+            except BaseException as e:
+                failure = e
+        if distributed:                                   # every rank follows rank 0's early-stopping decision — or its failure
+            flag = [stop, best_score, None if failure is None else repr(failure)]
             dist.broadcast_object_list(flag, src=0)
-            stop, best_score = flag
+            stop, best_score, remote_failure = flag
+            if rank != 0 and remote_failure is not None:
+                raise RuntimeError(f"rank 0 failed in its validation / checkpoint section: {remote_failure}")
+        if failure is not None:
+            raise failure
         if stop:
             log.info("early stop")
             break

@@ -194,7 +194,7 @@ def test_host_side_of_the_input_pipeline(tmp_path):
         Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(tmp_path / f"{i}.jpg", quality=95)
         rows.append(f"{i}.jpg,{i - 1}")
     (tmp_path / "p.csv").write_text("\n".join(rows) + "\n")
-    ds = oi.ImagenetDataset(tmp_path / "p.csv", tmp_path, train=False, loss_type="entropic")
+    ds = oi.CanvasDataset(tmp_path / "p.csv", tmp_path, train=False, loss_type="entropic")
     assert len(ds) == 2 and ds.table.label_count == 2 and ds.table.has_negatives()
     canvas, crop, flip, label = ds[0]
     assert canvas.shape == (256, 256, 3) and canvas.dtype == torch.uint8 and crop.dtype == torch.int32 and int(flip) == 0 and int(label) == -1
@@ -203,9 +203,9 @@ def test_host_side_of_the_input_pipeline(tmp_path):
     ref = np.asarray(img.crop((x0, y0, x0 + 224, y0 + 224)))
     cx, cy = (int(v) for v in crop)
     assert np.array_equal(canvas.numpy()[cy:cy + 224, cx:cx + 224], ref)
-    x, y = oi.ImagenetDataset(tmp_path / "p.csv", tmp_path, train=False, loss_type="entropic", uint8=False)[0]   # the reference's own sample
+    x, y = oi.CanvasDataset(tmp_path / "p.csv", tmp_path, train=False, loss_type="entropic", uint8=False)[0]   # the reference's own sample
     assert x.shape == (3, 224, 224) and torch.equal(x, torch.from_numpy(ref.copy()).permute(2, 0, 1).float().div(255))
-    garbage = oi.ImagenetDataset(tmp_path / "p.csv", tmp_path, train=True, loss_type="garbage")
+    garbage = oi.CanvasDataset(tmp_path / "p.csv", tmp_path, train=True, loss_type="garbage")
     assert int(garbage[0][3]) == 1 and garbage.table.label_count == 2     # -1 relabelled to the last index (dataset.py:60-68)
 
 
@@ -232,10 +232,52 @@ def test_dist_environment_and_launcher(monkeypatch, tmp_path):
         def __init__(self, cmd, env):
             started.append((cmd, {k: env[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
 
-        def wait(self):
+        def poll(self):
             return 0
     monkeypatch.setattr(cli.subprocess, "Popen", lambda cmd, env: FakeProc(cmd, env))
     assert cli.main([str(y), "2", "-g", "--nice", "0"]) == 0
     assert [e["RANK"] for _, e in started] == ["0", "1"] and all(e["WORLD_SIZE"] == "2" and e["MASTER_ADDR"] == "127.0.0.1" and
                                                                e["MASTER_PORT"] == "8889" for _, e in started)
     assert started[0][0][1:3] == ["-m", "openset_imagenet.script.train"] and started[0][0][3:] == [str(y), "2", "-g", "--nice", "0"]
+
+
+def test_launcher_terminates_the_surviving_ranks_when_one_dies():
+    """A rank that dies must not leave its siblings parked in a collective until the process-group timeout: the launcher polls,
+    terminates the exact children it started on the first non-zero exit and reports every exit code."""
+    import subprocess, sys, time
+    from openset_imagenet.script import train as cli
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"]),
+             subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(3)"])]
+    with pytest.raises(SystemExit) as e:
+        cli._wait_ranks(procs, poll_seconds=0.05, grace_seconds=5.0)
+    assert time.time() - t0 < 30 and all(p.poll() is not None for p in procs)
+    assert "3" in str(e.value) and "-15" in str(e.value)          # the dead rank's code and the survivor's SIGTERM
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
+    assert cli._wait_ranks(ok, poll_seconds=0.05) == 0
+
+
+def test_imagenet_dataset_has_the_reference_constructor_and_members(tmp_path):
+    """`ImagenetDataset(csv_file, imagenet_path, transform=None)` as reference-style callers use it (reference dataset.py:13-86):
+    (image, label) samples with the transform applied to the PIL image, label_count counting the -1 class (dataset.py:26), the two
+    label rewrites and the class weights of SURVEY Appendix B.5 (18 / (count * 4) -> [1.125, 0.9, 0.75, 1.5])."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    labels = [-1] * 3 + [0] * 4 + [1] * 5 + [2] * 6
+    rows = []
+    for i, lab in enumerate(labels):
+        Image.fromarray(rng.integers(0, 256, size=(20, 24, 3), dtype=np.uint8)).save(tmp_path / f"{i}.png")
+        rows.append(f"{i}.png,{lab}")
+    (tmp_path / "d.csv").write_text("\n".join(rows) + "\n")
+    to_tensor = lambda im: torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float().div(255)
+    ds = oi.ImagenetDataset(tmp_path / "d.csv", tmp_path, transform=to_tensor)
+    assert len(ds) == 18 and ds.label_count == 4 and list(ds.unique_classes) == [-1, 0, 1, 2] and ds.has_negatives()
+    x, y = ds[torch.tensor(0)]
+    assert x.shape == (3, 20, 24) and y.dtype == torch.int64 and int(y) == -1
+    assert oi.ImagenetDataset(tmp_path / "d.csv", tmp_path)[3][0].size == (24, 20)        # no transform: the PIL image itself
+    ds.replace_negative_label()
+    assert list(ds.unique_classes) == [0, 1, 2, 3] and int(ds[0][1]) == 3 and ds.label_count == 4 and not ds.has_negatives()
+    assert np.allclose(ds.calculate_class_weights().numpy(), [1.125, 0.9, 0.75, 1.5])
+    ds2 = oi.ImagenetDataset(tmp_path / "d.csv", tmp_path)
+    ds2.remove_negative_label()
+    assert len(ds2) == 15 and ds2.label_count == 3 and list(ds2.unique_classes) == [0, 1, 2] and int(ds2[0][1]) == 0
