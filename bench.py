@@ -75,14 +75,27 @@ def _cpu_leg(C, p_neg, loss, steps, B):
 def cpu_baseline(C, p_neg, steps=2, B=32):
     """The CPU oracle (torch-CPU restatement of the reference path) timed on this host's cores, the two legs SURVEY.md §8(d) names:
     the GPU workload's own loss at B = 32 (`value`) and BASELINE.json config 1 (Protocol 1, C = 116, softmax cross-entropy, B = 32)."""
-    best, ips = _cpu_leg(C, p_neg, "entropic", steps, B)
-    best1, ips1 = _cpu_leg(116, 0.0, "softmax", 1, B)
-    return {"value": round(ips, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    # SURVEY.md §8(d): torch.set_num_threads(os.cpu_count()) — bounded by the CPUs this process may actually run on (a GPU box
+    # hands each lease a share of the host), because threads beyond the affinity mask only oversubscribe the cores
+    default_threads = torch.get_num_threads()
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    want = max(1, min(os.cpu_count() or 1, usable))
+    torch.set_num_threads(want)
+    try:
+        best, ips = _cpu_leg(C, p_neg, "entropic", steps, B)
+        best1, ips1 = _cpu_leg(116, 0.0, "softmax", 1, B)
+        used = torch.get_num_threads()
+    finally:
+        torch.set_num_threads(default_threads)
+    return {"value": round(ips, 3), "unit": "images/sec", "cores": used, "kind": "port",
+            "threads": {"used": used, "set_num_threads_applied": True, "requested": want, "torch_default": default_threads,
+                        "host_cpu_count": os.cpu_count(), "affinity_cpus": usable,
+                        "rule": "torch.set_num_threads(min(os.cpu_count(), CPUs in this process's affinity mask)) — SURVEY.md §8(d)"},
             "sample": f"{steps} timed steps (after 1 warm-up) of batch {B}, same shapes/loss as the GPU workload, best step {best:.2f} s; "
                       f"oracle/resnet50_oracle.py (torch-CPU fp32 restatement; the reference package itself is not importable offline)",
             "config1_protocol1_softmax_b32": {"value": round(ips1, 3), "unit": "images/sec",
-                                              "sample": f"1 timed step (after 1 warm-up) of batch {B}, C = 116, softmax cross-entropy, Adam; "
-                                                        f"step {best1:.2f} s (BASELINE.json configs[0])"},
+                                              "sample": f"1 timed step (after 1 warm-up, i.e. a single measurement, not a best-of) of batch {B}, "
+                                                        f"C = 116, softmax cross-entropy, Adam; step {best1:.2f} s (BASELINE.json configs[0])"},
             "host_cpu_count": os.cpu_count()}
 
 
@@ -135,11 +148,41 @@ def parity_probe(model, C, device):
             "probe": "train-mode forward, batch 8 at 224x224, shared weights at initialisation"}
 
 
+def rccl_proof(model, net, backend, world, local, dev):
+    """What lets a SCALE record PROVE that N distinct GPUs took part: every rank's device identity gathered over the process
+    group itself, the communicator's backend / version and the per-step payload. Two ranks on one device under RCCL is an error
+    (reference intent: one process per GPU, config/train.yaml:18,35-39)."""
+    props = torch.cuda.get_device_properties(dev)
+    ident = {"rank": int(os.environ.get("RANK", "0")), "local_rank": local, "device_index": dev.index,
+             "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+             "pci_device_id": getattr(props, "pci_device_id", None), "name": props.name, "pid": os.getpid()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, ident)
+    key = lambda d: d["uuid"] if d["uuid"] and set(d["uuid"]) - set("0-") else (d["pci_bus_id"], d["pci_device_id"], d["device_index"])
+    distinct = len({key(d) for d in everyone})
+    used = dist.get_backend()
+    if backend == "nccl":
+        assert used == "nccl", f"bench.py measures RCCL: the process group reports backend {used!r}"
+        if distinct != world:
+            raise SystemExit(f"bench.py: {world} ranks but only {distinct} distinct GPUs ({[key(d) for d in everyone]}): one process per GPU")
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    buckets = model.gradient_buckets()
+    return {"world": world, "effective_world_for_averaging": net.sync.world, "backend": used, "distinct_devices": distinct,
+            "devices": [{k: d[k] for k in ("rank", "device_index", "uuid", "pci_bus_id", "name")} for d in everyone],
+            "nccl_version": ver, "allreduce_bytes_per_step": int(sum(4 * (hi - lo) for lo, hi in buckets)),
+            "buckets": [{"floats": int(hi - lo), "bytes": int(4 * (hi - lo))} for lo, hi in buckets],
+            "collective": "all_reduce(AVG) per backward stage on a contiguous slice of the gradient arena, async beside the remaining backward"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; the median window is reported")
     ap.add_argument("--workload", default="p2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -214,21 +257,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    rccl = rccl_proof(model, net, backend, world, local, dev) if use_dp else None
     parity = parity_probe(model, C, dev) if (world == 1 and not args.no_cpu_baseline) else None
     for _ in range(args.warmup):
         step()
     handle = model._net(B, 224, 224).h
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    # Three back-to-back windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and reduced with
+    # MAX over the ranks; the MEDIAN window is the reported one (`value`, `ms_per_step`), all three are listed. One 0.7 s window
+    # moves by +-1.5 % between identical runs; the median of three resolves ~1 % levers with the same `steps` per window.
+    windows = []
+    for _ in range(args.windows):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = step()
+        fence()
+        w = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([w], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = float(t)
+        windows.append(w)
+    elapsed = sorted(windows)[len(windows) // 2]
     loss_value = float(last.detach())
+    if use_dp:     # communication leg: the same step with every bucket's collective bracketed by events (outside the timed windows)
+        net.sync.timing(True)
+        for _ in range(max(1, min(args.steps, 5))):
+            step()
+        torch.cuda.synchronize()
+        comm = net.sync.read_timing()
+        net.sync.timing(False)
+        rccl.update(comm_ms_per_step=None if comm["comm_ms_per_step"] is None else round(comm["comm_ms_per_step"], 3),
+                    per_bucket_comm_ms=None if comm["per_bucket_ms"] is None else [round(v, 3) for v in comm["per_bucket_ms"]],
+                    exposed_comm_ms=None if comm["exposed_comm_ms"] is None else round(comm["exposed_comm_ms"], 3),
+                    comm_steps=comm["steps"],
+                    comm_how="instrumented steps after the timed windows: each bucket's all_reduce issued from a dedicated stream between two "
+                             "HIP events (its duration incl. the wait for the bucket's producer); exposed = compute-stream wait in finish() "
+                             "after the whole backward was enqueued")
     # Roofline leg: the same step, right after the timed region, with one HIP event after every executor op on the launch
     # stream. The instrumented mode keeps every kernel on that one stream (weight gradients are NOT moved to the side stream),
     # so each class's duration is its own; the headline `value` above comes from the un-instrumented, overlapped steps.
@@ -252,7 +317,9 @@ def main():
         out = {
             "metric": "images/sec (whole node) ResNet-50 + entropic-open-set, Protocol 2, 1/2/4/8 GPUs",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 3), "windows_ms_per_step": [round(w / args.steps * 1e3, 3) for w in windows],
+            "timing": f"median of {len(windows)} back-to-back windows of {args.steps} steps each (barrier + synchronize around every window, "
+                      "MAX over ranks per window)", "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (device-resident U[0,1) images, random-init weights seed 42)",
             "config": {"workload": wl["name"], "workload_key": args.workload, "classes": C, "batch_per_gpu": B, "global_batch": B * world, "image": "3x224x224",
                        "loss": wl["loss"], "optimizer": "adam lr=1e-3", "parallelism": f"dp{world}"},
@@ -283,6 +350,8 @@ def main():
                                   "tflops": round(B * g / v["ms_per_step"], 2) if g else None}
                               for (k, v), g in zip(prof.items(), (CONV_GFLOP_FWD, CONV_GFLOP_DGRAD, CONV_GFLOP_WGRAD, 0, 0, 0))},
             }
+        if rccl is not None:
+            out["rccl"] = rccl
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, wl["p_neg"])
             out["parity"] = parity

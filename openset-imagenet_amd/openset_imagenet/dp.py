@@ -20,19 +20,49 @@ from torch import nn
 
 
 class GradSync:
-    """Bucketed asynchronous gradient averaging over a flat arena."""
+    """Bucketed asynchronous gradient averaging over a flat arena.
+
+    `timing(True)` switches to an instrumented form of the same schedule (bench.py's comm leg, never the timed region): each
+    bucket's collective is issued from a communication stream this object owns, bracketed by two HIP events on that stream
+    (ProcessGroupNCCL runs the ring on its internal stream and makes the issuing stream wait for it, so the bracket is the
+    collective's own duration plus its wait for the bucket's producer), and `finish()` measures how long the compute stream
+    still had to wait once backward was fully enqueued — the exposed part. `read_timing()` returns the per-step means."""
 
     def __init__(self, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.backend = dist.get_backend(process_group)
         self._work = []
+        self._timing = False
+        self._comm_stream = None
+        self._ev = []            # per step: ([(start, end) per bucket], exposed_start, exposed_end)
+        self._cur = None
+        self._host = []          # gloo: host-side seconds per step (collectives complete on the host)
+
+    def timing(self, on):
+        self._timing = bool(on)
+        self._ev, self._host, self._cur = [], [], None
 
     def bucket_ready(self, flat, lo, hi):
         if self.world == 1 or hi <= lo:
             return
         bucket = flat[lo:hi]
         if self.backend == "nccl":
+            if self._timing and bucket.is_cuda:
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream(device=bucket.device)
+                comm = self._comm_stream
+                comm.wait_stream(torch.cuda.current_stream(bucket.device))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(comm):
+                    e0.record(comm)
+                    dist.all_reduce(bucket, op=dist.ReduceOp.AVG, group=self.group)
+                    e1.record(comm)
+                if self._cur is None:
+                    self._cur = []
+                self._cur.append((e0, e1))
+                self._work.append((None, None))
+                return
             w = dist.all_reduce(bucket, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             self._work.append((w, None))
         else:
@@ -40,11 +70,42 @@ class GradSync:
             self._work.append((w, bucket))
 
     def finish(self):
+        timed_dev = self._timing and self._comm_stream is not None and self._cur is not None
+        if timed_dev:
+            cur = torch.cuda.current_stream(self._comm_stream.device)
+            x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            x0.record(cur)
+            cur.wait_stream(self._comm_stream)
+            x1.record(cur)
+            self._ev.append((self._cur, x0, x1))
+            self._cur = None
+        t0 = None
+        if self._timing and not timed_dev and self._work:
+            import time
+            t0 = time.perf_counter()
         for w, bucket in self._work:
-            w.wait()  # nccl: the current stream waits for the side stream; gloo: host wait
+            if w is not None:
+                w.wait()  # nccl: the current stream waits for the side stream; gloo: host wait
             if bucket is not None:
                 bucket.div_(self.world)
+        if t0 is not None:
+            import time
+            self._host.append(time.perf_counter() - t0)
         self._work = []
+
+    def read_timing(self):
+        """{"steps", "comm_ms_per_step", "per_bucket_ms", "exposed_comm_ms"} over the instrumented steps since timing(True);
+        synchronises on the recorded events. gloo: only the exposed (host wait) time exists."""
+        if self._ev:
+            self._ev[-1][2].synchronize()
+            nb = len(self._ev[0][0])
+            per = [sum(st[0][i][0].elapsed_time(st[0][i][1]) for st in self._ev) / len(self._ev) for i in range(nb)]
+            exposed = sum(st[1].elapsed_time(st[2]) for st in self._ev) / len(self._ev)
+            return {"steps": len(self._ev), "comm_ms_per_step": sum(per), "per_bucket_ms": per, "exposed_comm_ms": exposed}
+        if self._host:
+            return {"steps": len(self._host), "comm_ms_per_step": None, "per_bucket_ms": None,
+                    "exposed_comm_ms": 1e3 * sum(self._host) / len(self._host)}
+        return {"steps": 0, "comm_ms_per_step": None, "per_bucket_ms": None, "exposed_comm_ms": None}
 
 
 class DistributedDataParallel(nn.Module):

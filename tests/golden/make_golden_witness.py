@@ -12,7 +12,13 @@ Outputs (tests/golden/resnet_witness.npz): for each case, in float64, train mode
   pooled [B, 2048]  = ResNetModel(...).pooler_output           (the body: stem, 16 bottlenecks, global average pool)
   features, logits  = the reference head (model.py:19-26,37-39) applied to `pooled` with torch.nn.functional.linear
   bn running_mean / running_var of three BatchNorms after the train-mode forward (momentum / unbiased-variance rule)
-tests/test_oracle.py::test_oracle_body_matches_transformers_witness compares oracle.forward against these arrays.
+  gradients (round 3): autograd is enabled on the transformers module in train mode and a fixed scalar — the entropic open-set
+  loss (reference losses.py:16-29, closed form in oracle/losses_oracle.py, itself pinned to the reference's vectors) of the
+  witness logits with seeded labels — is back-propagated through it (the reference side: j.backward(), train.py:138). Committed in
+  float64: the L2 norm of all 162 parameter gradients, the full gradient of conv1, of conv1 / bn1 of block 0 of every stage (the
+  two largest as strided samples, see GRAD_FULL / GRAD_SAMPLED), of the last BatchNorm, of fc and of the logits layer. The oracle's
+  backward graph is thereby pinned by an implementation that shares no code with it.
+tests/test_oracle.py::test_oracle_body_matches_transformers_witness compares oracle.forward / forward_backward against these arrays.
 
 Run: python tests/golden/make_golden_witness.py
 """
@@ -31,6 +37,14 @@ from oracle import resnet50_oracle as R  # noqa: E402
 
 CASES = (("b4_64_c30", 4, 64, 30, 101), ("b2_96_c116", 2, 96, 116, 102))
 WATCHED_BN = ("resnet_base.bn1", "resnet_base.layer2.0.downsample.1", "resnet_base.layer4.2.bn3")
+GRAD_FULL = ("resnet_base.conv1.weight", "resnet_base.bn1.weight", "resnet_base.bn1.bias",
+             "resnet_base.layer1.0.conv1.weight", "resnet_base.layer1.0.bn1.weight", "resnet_base.layer1.0.bn1.bias",
+             "resnet_base.layer1.0.downsample.0.weight", "resnet_base.layer2.0.bn1.weight",
+             "resnet_base.layer2.3.bn2.bias", "resnet_base.layer3.0.bn1.weight", "resnet_base.layer3.5.bn3.weight",
+             "resnet_base.layer4.0.bn1.bias", "resnet_base.layer4.2.bn3.weight", "resnet_base.layer4.2.bn3.bias",
+             "resnet_base.fc.bias", "logits.weight")
+GRAD_SAMPLED = {"resnet_base.fc.weight": 5, "resnet_base.layer2.0.conv1.weight": 3, "resnet_base.layer3.0.conv1.weight": 7, "resnet_base.layer3.2.conv2.weight": 53, "resnet_base.layer4.0.conv1.weight": 31,
+                "resnet_base.layer4.1.conv2.weight": 211, "resnet_base.layer4.0.downsample.0.weight": 97}   # every n-th element, flattened OIHW
 
 
 def hf_key(k):
@@ -83,6 +97,34 @@ def main():
                     out[p + bn + ".running_mean"] = hsd[hf_key(bn + ".running_mean")].clone().numpy()   # state_dict tensors alias the buffers
                     out[p + bn + ".running_var"] = hsd[hf_key(bn + ".running_var")].clone().numpy()
                     assert int(hsd[hf_key(bn + ".num_batches_tracked")]) == 1
+        # ---- gradients: the transformers module under autograd, train mode, the entropic loss of its logits -------------------
+        from oracle import losses_oracle as L
+        hf.load_state_dict(body, strict=True)
+        hf.train(True)
+        for q in hf.parameters():
+            q.requires_grad_(True)
+            q.grad = None
+        head = {"resnet_base.fc.weight": fcw.clone().requires_grad_(True), "resnet_base.fc.bias": fcb.clone().requires_grad_(True),
+                "logits.weight": lw.clone().requires_grad_(True)}
+        y = torch.randint(-1, C, (B,), generator=torch.Generator().manual_seed(seed + 1000))
+        pooled = hf(x.double()).pooler_output.flatten(1)
+        logits = F.linear(F.linear(pooled, head["resnet_base.fc.weight"], head["resnet_base.fc.bias"]), head["logits.weight"])
+        loss = L.entropic_openset_loss(logits, y, 1.0)
+        loss.backward()
+        hfp = dict(hf.named_parameters())
+        grads = {}
+        for k in R.param_keys(sd):
+            grads[k] = head[k].grad if k in head else hfp[hf_key(k)].grad
+            assert grads[k] is not None and grads[k].shape == sd[k].shape, k
+        keys = R.param_keys(sd)
+        assert len(keys) == 162
+        out[tag + ".grad.labels"] = y.numpy()
+        out[tag + ".grad.loss"] = np.array(float(loss))
+        out[tag + ".grad.norms"] = np.array([float(grads[k].norm()) for k in keys])
+        for k in GRAD_FULL:
+            out[f"{tag}.grad.full.{k}"] = grads[k].detach().numpy().copy()
+        for k, n in GRAD_SAMPLED.items():
+            out[f"{tag}.grad.every{n}.{k}"] = grads[k].detach().flatten()[::n].numpy().copy()
         out[tag + ".meta"] = np.array([B, HW, C, seed])
         print(tag, "pooled", tuple(out[f"{tag}.train.pooled"].shape), "max |logit|", float(np.abs(out[f"{tag}.train.logits"]).max()))
     np.savez_compressed(os.path.join(HERE, "resnet_witness.npz"), **out)

@@ -52,6 +52,17 @@ def _worker(rank, world, port, out):
         ddp.sync.finish()
         assert torch.allclose(model.flat_gradients(), expect, rtol=0, atol=1e-7)
         assert sorted(buckets)[0][0] == 0 and max(h for _, h in buckets) == mine.numel()
+        # instrumented form of the same schedule (bench.py's comm leg): same averages, and the timing record has its fields
+        with torch.no_grad():
+            model.flat_gradients().copy_(mine)
+        ddp.sync.timing(True)
+        for lo, hi in buckets:
+            ddp.sync.bucket_ready(model.flat_gradients(), lo, hi)
+        ddp.sync.finish()
+        t = ddp.sync.read_timing()
+        ddp.sync.timing(False)
+        assert torch.allclose(model.flat_gradients(), expect, rtol=0, atol=1e-7)
+        assert t["steps"] == 1 and t["exposed_comm_ms"] is not None and t["exposed_comm_ms"] >= 0 and t["comm_ms_per_step"] is None
         out.put((rank, float((model.flat_gradients() - expect).abs().max())))
     finally:
         dist.destroy_process_group()

@@ -36,3 +36,60 @@ def test_two_ranks_share_one_gpu(cuda):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
         assert f"rank {rank}: ok" in out
+
+
+def _run_bench(extra_args, env_extra, nproc):
+    import json
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    port = _free_port()
+    procs = []
+    for rank in range(nproc):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+        if nproc > 1:
+            env.update(RANK=str(rank), WORLD_SIZE=str(nproc), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(nproc), *extra_args], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=500))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for rank, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{e[-3000:]}"
+    lines = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py prints exactly one JSON line on rank 0's stdout"
+    assert all(not o.strip() for o, _ in outs[1:]), "only rank 0 prints"
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_rank_rehearsal_reports_the_proof_of_ranks(cuda):
+    """bench.py as the driver launches it for N = 2 (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment), rehearsed on the one GPU of the test box with gloo carrying the collectives (OSI_BENCH_BACKEND=gloo; under RCCL
+    two ranks on one device make bench.py exit with an error). The JSON line carries the three timed windows with their median as
+    `value`, and the `rccl` object a SCALE record needs to prove that N processes on N devices took part."""
+    out = _run_bench(["--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-profile"], {"OSI_BENCH_BACKEND": "gloo"}, 2)
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    w = out["windows_ms_per_step"]
+    assert len(w) == 3 and sorted(w)[1] == out["ms_per_step"]
+    assert abs(out["value"] - 2 * 8 / (out["ms_per_step"] * 1e-3)) <= 0.01 * out["value"]
+    r = out["rccl"]
+    assert r["world"] == 2 and r["backend"] == "gloo" and len(r["devices"]) == 2 and r["distinct_devices"] == 1   # the rehearsal shares GPU 0
+    assert [d["rank"] for d in r["devices"]] == [0, 1]
+    assert len(r["buckets"]) == 4 and r["allreduce_bytes_per_step"] == sum(b["bytes"] for b in r["buckets"]) == 4 * 23570402
+    assert r["exposed_comm_ms"] is not None and r["comm_steps"] >= 1
+
+
+@pytest.mark.timeout(900)
+def test_bench_force_dp_world1_runs_the_rccl_path(cuda):
+    """N = 1 with --force-dp: a world-1 RCCL communicator, the staged backward and one all_reduce per bucket, each bracketed by HIP
+    events in the communication leg."""
+    out = _run_bench(["--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-profile", "--force-dp"], {}, 1)
+    r = out["rccl"]
+    assert r["world"] == 1 and r["backend"] == "nccl" and r["distinct_devices"] == 1 and r["nccl_version"]
+    assert len(r["per_bucket_comm_ms"]) == 4 and all(v >= 0 for v in r["per_bucket_comm_ms"])
+    assert r["comm_ms_per_step"] == pytest.approx(sum(r["per_bucket_comm_ms"]), abs=2e-3) and r["exposed_comm_ms"] >= 0
+    assert len(out["windows_ms_per_step"]) == 3

@@ -177,6 +177,32 @@ def test_oracle_body_matches_transformers_witness(golden_dir):
         work = {k: v.clone() for k, v in sd.items()}
         lg32, _ = R.forward(work, x.float(), True)
         assert float(np.abs(lg32.double().numpy() - W[f"{tag}.train.logits"]).max()) <= 1e-4
+        # backward: the witness's autograd gradients of the entropic loss (fp64) against the oracle's, all 162 norms + the committed
+        # tensors / strided samples. Both sides are fp64 with the same decisions (no pre-activation sits within 1e-16 of zero), so
+        # the bar is summation-order noise: 1e-8 relative.
+        y = torch.from_numpy(W[f"{tag}.grad.labels"])
+        work = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        _, _, loss, grads = R.forward_backward(work, x, y, lambda lg, t, f: L.entropic_openset_loss(lg, t, 1.0))
+        assert abs(float(loss) - float(W[f"{tag}.grad.loss"])) <= 1e-12 * max(1.0, abs(float(loss)))
+        keys = R.param_keys(sd)
+        norms = np.array([float(grads[k].norm()) for k in keys])
+        assert norms.shape == W[f"{tag}.grad.norms"].shape == (162,)
+        assert np.allclose(norms, W[f"{tag}.grad.norms"], rtol=1e-8, atol=1e-14), tag
+        checked = 0
+        for key in W.files:
+            if key.startswith(f"{tag}.grad.full."):
+                k = key[len(f"{tag}.grad.full."):]
+                got = grads[k].numpy()
+            elif key.startswith(f"{tag}.grad.every"):
+                n, k = key[len(f"{tag}.grad.every"):].split(".", 1)
+                got = grads[k].flatten()[::int(n)].numpy()
+            else:
+                continue
+            ref = W[key]
+            assert got.shape == ref.shape, key
+            assert float(np.abs(got - ref).max()) <= 1e-8 * float(np.abs(ref).max()) + 1e-16, key
+            checked += 1
+        assert checked >= 20
 
 
 def test_host_classes_match_reference_traces(golden_dir, tmp_path):
