@@ -67,6 +67,11 @@ struct ConvP {
     const float* in_shift;
     const float* res;     // fwd XF = 2: shortcut tensor added before the ReLU (same shape as x)
     size_t slab_stride;
+    // fwd / dgrad, balanced remainder (see plan_tail_split): row tiles mt < MT1 are computed at full K by blocks [0, g1); the last
+    // MT - MT1 row tiles are split ks_S ways along K by the blocks behind them, each writing its raw 64x64 accumulator tile to
+    // ks_slab[((mt - MT1) * NT + nt) * ks_S + split]; k_conv_tail_fixup adds the splits in fixed order and finishes the epilogue
+    int MT1, g1, ks_S, ks_T;
+    float* ks_slab;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -88,6 +93,26 @@ __device__ __forceinline__ bool tile_of_block(int bid, int MT, int NT, int& mt, 
     nt = slot % NT;
     mt = (slot / NT) * 8 + xcd;
     return mt < MT;
+}
+
+// Balanced remainder. A launch of V = MT x NT tiles on a chip of N CUs runs floor(V / N) full rounds plus a ragged one in which
+// V mod N CUs hold one workgroup more than the rest — at 3-6 workgroups per CU (the 14x14 / 7x7 layers at batch 128) that is
+// 12-25 % of the launch. The tiles of the ragged round (the last row tiles) are therefore split along K into S = floor(N / tiles)
+// short workgroups each, so that every CU ends up with the same number of full-K workgroups plus (at most) one short one. Only those
+// few tiles go through a slab + fix-up pass (a few MB), everything else keeps its single-pass epilogue. Deterministic: the splits
+// are summed in fixed order. Returns false for a block that has nothing to do.
+__device__ __forceinline__ bool tile_of_block_split(const ConvP& p, int bid, int& mt, int& nt, int& ks) {
+    ks = -1;
+    if (p.ks_S <= 1) return tile_of_block(bid, p.MT, p.NT, mt, nt);
+    if (bid < p.g1) return tile_of_block(bid, p.MT1, p.NT, mt, nt);
+    const int pb = bid - p.g1;
+    const int xcd = pb & 7, slot = pb >> 3;
+    nt = slot % p.NT;
+    const int key = (slot / p.NT) * 8 + xcd;       // (remainder row tile, split): the NT column tiles of a key share the A slice on one XCD
+    const int mt2 = key / p.ks_S;
+    ks = key - mt2 * p.ks_S;
+    mt = p.MT1 + mt2;
+    return mt < p.MT;
 }
 
 // ---- MFMA over one LDS stage -------------------------------------------------------------------------
@@ -169,7 +194,9 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 //         shortcut + ReLU) recomputed in the loader, so conv1 of the NEXT bottleneck need not wait for the block-output pass
 // (the fused forms pin the register budget of their plain twins — 8 / 5 waves per SIMD — so that the extra loader work cannot
 // cost occupancy, which is what these kernels live on)
-template <int WM, int WN, bool STEM, int NST, int XF = 0>
+// KS: the launch carries a K-split tail (tile_of_block_split); its own instantiation so that the plain kernels keep their scalar
+// register count (<= 80 SGPRs = eight resident 256-thread workgroups per CU)
+template <int WM, int WN, bool STEM, int NST, int XF = 0, bool KS = false>
 __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2)) void k_conv_fwd(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32, BR = BN / 32;  // float4 loads per thread per stage
@@ -186,8 +213,10 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
         // visible to every wave after the first __syncthreads() below (before any sstore of transformed data is read)
     }
 
-    int mt, nt;
-    if (!tile_of_block(blockIdx.x, p.MT, p.NT, mt, nt)) return;
+    static_assert(!KS || (WM == 1 && WN == 1 && !STEM && NST == 1), "the K-split tail is built for the single-buffered 64x64 tile");
+    int mt, nt, ks = -1;
+    if (KS) { if (!tile_of_block_split(p, blockIdx.x, mt, nt, ks)) return; }
+    else if (!tile_of_block(blockIdx.x, p.MT, p.NT, mt, nt)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -235,8 +264,14 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
 
-    const int T = p.Ktot / BK;
+    const int Tall = p.Ktot / BK;
+    const int t0 = (!KS || ks < 0) ? 0 : ks * p.ks_T;            // this workgroup's K tiles [t0, T)
+    const int T = (!KS || ks < 0) ? Tall : min(Tall, t0 + p.ks_T);
     int r = 0, s = 0, c0 = 0;  // current tap / channel offset (non-stem)
+    if (KS && !STEM && ks > 0 && !p.unit) {
+        const int tap = (t0 * BK) / p.Cin;
+        c0 = t0 * BK - tap * p.Cin; r = tap / p.S; s = tap - r * p.S;
+    }
     int ld_c0 = 0, ld_tap = 0; // XF: channel offset / tap index of the tile sitting in ra (set by gload, used by sstore)
     f32x4 ra[AR], rb[BR];
     f32x4 rr[XF == 2 ? AR : 1];   // XF = 2: the shortcut rows of the tile sitting in ra
@@ -301,12 +336,12 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
         for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(sB + (lr + 32 * i) * LDR + kq * 4) = rb[i];
     };
 
-    gload(0); advance();
+    gload(t0); advance();
     if (XF) __syncthreads();   // the scale / shift tables are complete
     sstore(0);
     __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        const int buf = NST == 2 ? (t & 1) : 0;
+    for (int t = t0; t < T; ++t) {
+        const int buf = NST == 2 ? ((t - t0) & 1) : 0;
         if (t + 1 < T) { gload(t + 1); advance(); }
         const float* sA = smem + buf * STAGE;
         mma_RR<WM, WN>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
@@ -317,6 +352,22 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
 
     bool stored = false;
     if constexpr (WM == 1 && WN == 1) {
+        if (KS && ks >= 0) {
+            // K split of a remainder tile: the raw accumulators go to the slab as a dense 64x64 tile (16-byte stores through the
+            // same LDS transpose as below); output, statistics and row bounds are the fix-up pass's business
+            constexpr int LDT = BN + 4;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) smem[(wm * 32 + acc_row(rr, lane)) * LDT + wn * 32 + (lane & 31)] = acc[0][0][rr];
+            __syncthreads();
+            float* dst = p.ks_slab + ((size_t)((mt - p.MT1) * p.NT + nt) * p.ks_S + ks) * (BM * BN);
+            const int c4 = tid & 15, rg = tid >> 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rl = rg + 16 * k;
+                *reinterpret_cast<f32x4*>(dst + rl * BN + c4 * 4) = *reinterpret_cast<const f32x4*>(smem + rl * LDT + c4 * 4);
+            }
+            return;
+        }
         if (!p.accumulate) {
             // 64x64 tile: transpose through LDS so each lane stores 16 bytes (4 consecutive channels of a pixel), see k_conv_dgrad
             constexpr int LDT = BN + 4;
@@ -1064,6 +1115,57 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
             }
 }
 
+// Fix-up pass of a forward launch with a K-split tail (tile_of_block_split): one workgroup per remainder tile adds the tile's
+// splits in split order (fixed: bitwise reproducible), writes the output rows and — like the convolution's own epilogue — the
+// BatchNorm partial (mean, M2) of the tile's 64 columns over its valid rows (two passes over the register-resident tile).
+__global__ __launch_bounds__(256) void k_conv_fwd_tail_fixup(ConvP p) {
+    __shared__ float red[16][64];
+    __shared__ float smean[64];
+    const int tile = blockIdx.x;
+    const int mt = p.MT1 + tile / p.NT, nt = tile - (tile / p.NT) * p.NT;
+    const int m0 = mt * 64, n0 = nt * 64;
+    const float* src = p.ks_slab + (size_t)tile * p.ks_S * 4096;
+    const int tid = threadIdx.x, c4 = tid & 15, rg = tid >> 4;
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int rl = rg + 16 * k;
+        f32x4 a = ld4(src + rl * 64 + c4 * 4);
+        for (int sp = 1; sp < p.ks_S; ++sp) a += ld4(src + (size_t)sp * 4096 + rl * 64 + c4 * 4);
+        v[k] = a;
+        if (m0 + rl < p.M) *reinterpret_cast<f32x4*>(p.y + (size_t)(m0 + rl) * p.Cout + n0 + c4 * 4) = a;
+    }
+    if (!p.pmean) return;
+    const float cnt = (float)min(64, p.M - m0);
+    f32x4 sm = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (m0 + rg + 16 * k < p.M) sm += v[k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rg][c4 * 4 + e] = sm[e];
+    __syncthreads();
+    if (tid < 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) a += red[g][tid];
+        smean[tid] = a / cnt;
+    }
+    __syncthreads();
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(smean + c4 * 4);
+    f32x4 q = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (m0 + rg + 16 * k < p.M) { const f32x4 d = v[k] - mu; q += d * d; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rg][c4 * 4 + e] = q[e];     // every thread read smean before this barrier pair's first barrier
+    __syncthreads();
+    if (tid < 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) a += red[g][tid];
+        p.pmean[(size_t)mt * p.Cout + n0 + tid] = smean[tid];
+        p.pm2[(size_t)mt * p.Cout + n0 + tid] = a;
+    }
+}
+
 // out[i] = sum_s slab[s][i]  (fixed order: bitwise reproducible)
 // One workgroup = 16 consecutive float4 outputs x 16 split lanes: lane j sums splits j, j+16, ... (4 independent loads in
 // flight), then the 16 lane partials are added in lane order. Many small dependent-latency chains instead of one long one.
@@ -1138,6 +1240,58 @@ static ConvP make_p(const osi_conv_desc* d) {
     p.dHoWo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
     p.dWo = make_fastdiv((uint32_t)d->Wo);
     return p;
+}
+
+// ---- balanced remainder: plan ------------------------------------------------------------------------------------------------
+static int chip_cus() {
+    static int n = 0;
+    if (g_osi_tuning.tail_cus > 0) return g_osi_tuning.tail_cus;
+    if (n == 0) {
+        int v = 0, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;      // MI355X
+    }
+    return n;
+}
+struct TailPlan { int MT1, S, ksT, tiles; };   // tiles = remainder tiles ((MT - MT1) * NT); S <= 1: no split
+// MT x NT tiles of 64x64, T K-tiles each. Splits the ragged last round when that buys at least ~4 % of the launch (the fix-up pass
+// and its launch boundary cost a few microseconds) and every split keeps at least 2 K tiles.
+static TailPlan plan_tail_split(long MT, int NT, int T) {
+    TailPlan t{(int)MT, 1, T, 0};
+    if (!g_osi_tuning.tail_split || T < 4) return t;
+    const long ncu = chip_cus(), V = MT * NT;
+    const long q = V / ncu, r = V - q * ncu;
+    if (r == 0 || q > 13) return t;
+    if ((double)(ncu - r) / (double)ncu / (double)(q + 1) < 0.04) return t;
+    long MT1 = q * ncu / NT;                       // full rounds, in whole row tiles
+    long rem = (MT - MT1) * NT;
+    long S = ncu / rem;
+    if (S > T / 2) S = T / 2;
+    if (S > 32) S = 32;
+    if (S <= 1) return t;
+    const int ksT = (int)((T + S - 1) / S);
+    S = (T + ksT - 1) / ksT;
+    if (S <= 1) return t;
+    t.MT1 = (int)MT1; t.S = (int)S; t.ksT = ksT; t.tiles = (int)rem;
+    return t;
+}
+static size_t tail_slab_floats(const TailPlan& t) { return t.S > 1 ? (size_t)t.tiles * t.S * 4096 : 0; }
+
+template <int XF>
+static int launch_fwd_split(ConvP p, const TailPlan& tp, float* slab, hipStream_t st) {
+    p.MT = osi_cdiv(p.M, 64); p.NT = p.Cout / 64;
+    p.MT1 = tp.MT1; p.ks_S = tp.S; p.ks_T = tp.ksT; p.ks_slab = slab;
+    p.g1 = osi_cdiv(p.MT1, 8) * 8 * p.NT;
+    const int keys = (p.MT - p.MT1) * tp.S;
+    const int grid = p.g1 + osi_cdiv(keys, 8) * 8 * p.NT;
+    size_t smem = (size_t)(64 + 64) * LDR * sizeof(float);
+    if (XF) smem += (size_t)2 * p.Cin * sizeof(float);
+    if (int e = set_smem(k_conv_fwd<1, 1, false, 1, XF, true>, smem)) return e;
+    hipLaunchKernelGGL((k_conv_fwd<1, 1, false, 1, XF, true>), dim3(grid), dim3(256), smem, st, p);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_conv_fwd_tail_fixup, dim3(tp.tiles), dim3(256), 0, st, p);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
 }
 
 template <int WM, int WN, bool STEM, int NST = 2, int XF = 0>
@@ -1325,10 +1479,22 @@ int osi_conv_fwd_act2(const osi_conv_desc* d, const float* x, const float* in_sc
     return conv_fwd_impl(d, x, w, y, tile, pstats, pstats_bytes, P, rows_per_block, stream, in_scale, in_shift, res);
 }
 
+// floats of the statistics part of the forward workspace (row-tile partials + finalize scratch), rounded to 256 B: the slab of a
+// K-split tail starts behind it
+static size_t fwd_stats_floats(const osi_conv_desc* d) {
+    const size_t n = (size_t)2 * osi_cdiv((long)d->B * d->Ho * d->Wo, 64) * d->Cout + (size_t)2 * 32 * d->Cout;
+    return (n + 63) / 64 * 64;
+}
+static TailPlan fwd_tail_plan(const osi_conv_desc* d) {
+    const long M = (long)d->B * d->Ho * d->Wo;
+    if (is_stem(d) || d->Cout % 64 || d->Cin % BK) return TailPlan{(int)osi_cdiv(M, 64), 1, 0, 0};
+    return plan_tail_split(osi_cdiv(M, 64), d->Cout / 64, d->R * d->S * d->Cin / BK);
+}
+
 size_t osi_conv_fwd_bnstats_workspace(const osi_conv_desc* d) {
     if (!desc_ok(d)) return 0;
-    // row-tile partials + the 32 group pairs of osi_bn_finalize_stats' first level
-    return ((size_t)2 * osi_cdiv((long)d->B * d->Ho * d->Wo, 64) * d->Cout + (size_t)2 * 32 * d->Cout) * sizeof(float);
+    // row-tile partials + the 32 group pairs of osi_bn_finalize_stats' first level [+ the slab of a K-split tail]
+    return (fwd_stats_floats(d) + tail_slab_floats(fwd_tail_plan(d))) * sizeof(float);
 }
 
 int osi_conv_fwd_bnstats(const osi_conv_desc* d, const float* x, const float* w, float* y, int tile, float* pstats,
@@ -1363,6 +1529,16 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
         return launch_fwd<2, 1, true>(p, st);
     }
     OSI_REQUIRE(d->Cin % BK == 0 && d->Cout % 64 == 0);
+    if (tile == OSI_TILE_AUTO && pstats) {
+        // ragged last round split along K (plan_tail_split) when the caller's workspace has room for the slab behind the statistics
+        const TailPlan tp = fwd_tail_plan(d);
+        if (tp.S > 1 && pstats_bytes >= (fwd_stats_floats(d) + tail_slab_floats(tp)) * sizeof(float)) {
+            if (int e = with_stats(64)) return e;
+            float* slab = pstats + fwd_stats_floats(d);
+            if (in_scale) return res ? launch_fwd_split<2>(p, tp, slab, st) : launch_fwd_split<1>(p, tp, slab, st);
+            return launch_fwd_split<0>(p, tp, slab, st);
+        }
+    }
     if (tile == OSI_TILE_AUTO) {
         // Measured on MI355X over the 22 ResNet-50 shapes at B=128 (tools/bench_conv.py, profiles/conv_layers_r01.txt): many
         // small workgroups (4 resident per CU) beat large tiles almost everywhere because the ragged last round of the launch is

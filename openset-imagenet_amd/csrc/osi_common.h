@@ -31,6 +31,8 @@ struct OsiTuning {
     int wgrad3_blocks;  // workgroups per launch the all-taps kernel's split-K plan aims for
     int fwd_wide, dgrad_wide;  // A/B: 64x128 forward / input-gradient tiles wherever the channel count allows (default 0: measured rule)
     int wgrad_group;    // weight-gradient block -> XCD mapping: 0 plain 2-D grid, 1 the R*S taps of a cell share an XCD, 2 whole K splits do
+    int tail_split;     // 1 = forward / input-gradient launches split the tiles of their ragged last round along K (plan_tail_split)
+    int tail_cus;       // CU count the tail plan balances for; 0 = ask the device (256 on MI355X)
 };
 extern OsiTuning g_osi_tuning;
 

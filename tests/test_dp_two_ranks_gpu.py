@@ -79,7 +79,9 @@ def test_bench_two_rank_rehearsal_reports_the_proof_of_ranks(cuda):
     r = out["rccl"]
     assert r["world"] == 2 and r["backend"] == "gloo" and len(r["devices"]) == 2 and r["distinct_devices"] == 1   # the rehearsal shares GPU 0
     assert [d["rank"] for d in r["devices"]] == [0, 1]
-    assert len(r["buckets"]) == 4 and r["allreduce_bytes_per_step"] == sum(b["bytes"] for b in r["buckets"]) == 4 * 23570402
+    # the four stage buckets tile the gradient arena: 23 570 402 parameters (C = 30), each tensor padded to 16 bytes
+    assert len(r["buckets"]) == 4 and r["allreduce_bytes_per_step"] == sum(b["bytes"] for b in r["buckets"])
+    assert 4 * 23570402 <= r["allreduce_bytes_per_step"] <= 4 * 23570402 + 16 * 162
     assert r["exposed_comm_ms"] is not None and r["comm_steps"] >= 1
 
 
