@@ -445,13 +445,100 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     }
 }
 
+// Epilogue of one 64x64 input-gradient tile, every lane owning 4 consecutive channels of a pixel (16-byte accesses): skip-connection
+// addend, ReLU gate (stored bitmask or recomputed from the producer's pre-BN tensor), output, and the per-row-tile BatchNorm-backward
+// partial sums of the consumer layer(s). `rd(row, c4)` returns the accumulated float4 of tile row `row`, channel quad `c4`: the
+// convolution kernel reads its LDS-transposed accumulators, the fix-up pass of a K-split tail sums the tile's slab entries. One
+// code path for both keeps their results identical in form (same gates, same reduction order inside the tile).
+template <bool FUSED, typename RD>
+__device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, int cls, int mt, int m0, int n0, int Mc, int st, int ph,
+                                                 int pw, const FastDiv& dHW, const FastDiv& dW, RD rd) {
+    constexpr int BN = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 15, rg = tid >> 4;
+    const int col = n0 + c4 * 4;
+    f32x4 sg = {0, 0, 0, 0}, s0 = sg, s1 = sg, mu0 = sg, is0 = sg, mu1 = sg, is1 = sg, gsc = sg, gsh = sg;
+    if (FUSED && p.esum) {
+        mu0 = ld4(p.emean0 + col); is0 = ld4(p.einv0 + col);
+        if (p.ey1) { mu1 = ld4(p.emean1 + col); is1 = ld4(p.einv1 + col); }
+    }
+    if (FUSED && p.escale0) { gsc = ld4(p.escale0 + col); gsh = ld4(p.eshift0 + col); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int rl = rg + 16 * k;
+        const int m = m0 + rl;
+        if (m >= Mc) continue;
+        uint32_t pix = (uint32_t)m;
+        if (st != 1) {
+            const uint32_t b = fdiv((uint32_t)m, dHW);
+            const uint32_t rem = (uint32_t)m - b * dHW.d;
+            const uint32_t h2 = fdiv(rem, dW), w2 = rem - h2 * dW.d;
+            pix = (b * p.H + (ph + st * h2)) * p.W + (pw + st * w2);
+        }
+        const uint32_t off = pix * p.Cin + col;
+        f32x4 v = rd(rl, c4);
+        if (p.addend) v += ld4(p.addend + off);   // may be the output buffer itself: read and written by the same lane
+        if (FUSED) {
+            if (p.ebits) {   // 1 bit / element: words (i4 >> 6) * 4 + component, bit i4 & 63 (bn.hip)
+                const uint32_t i4 = off >> 2;
+                const ulonglong2* wp = reinterpret_cast<const ulonglong2*>(p.ebits + (size_t)(i4 >> 6) * 4);
+                const ulonglong2 w01 = wp[0], w23 = wp[1];
+                const int bit = i4 & 63;
+                v[0] = (w01.x >> bit) & 1 ? v[0] : 0.f; v[1] = (w01.y >> bit) & 1 ? v[1] : 0.f;
+                v[2] = (w23.x >> bit) & 1 ? v[2] : 0.f; v[3] = (w23.y >> bit) & 1 ? v[3] : 0.f;
+            }
+            f32x4 y0v = {0, 0, 0, 0};
+            if (p.escale0 || p.esum) y0v = ld4(p.ey0 + off);
+            if (p.escale0) {   // the producer's activation was never stored: its ReLU gate is recomputed from the pre-BN tensor
+#pragma unroll               // with the very expression (one fma) the forward loader used
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(y0v[e], gsc[e], gsh[e]) > 0.f ? v[e] : 0.f;
+            }
+            if (p.esum) {    // BatchNorm-backward partial sums of the consumer(s): sum g, sum g*xhat0 [, sum g*xhat1]
+                sg += v;
+                s0 += (v * (y0v - mu0)) * is0;
+                if (p.ey1) s1 += (v * (ld4(p.ey1 + off) - mu1)) * is1;
+            }
+        }
+        *reinterpret_cast<f32x4*>(p.y + off) = v;
+    }
+    if (FUSED && p.esum) {
+        // rows of one channel quad: 4 lanes of the wave (lane bits 4, 5), then the 4 waves through LDS, in wave order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sg[e] += __shfl_xor(sg[e], 16, 64); s0[e] += __shfl_xor(s0[e], 16, 64); s1[e] += __shfl_xor(s1[e], 16, 64);
+            sg[e] += __shfl_xor(sg[e], 32, 64); s0[e] += __shfl_xor(s0[e], 32, 64); s1[e] += __shfl_xor(s1[e], 32, 64);
+        }
+        __syncthreads();   // every lane is done reading the transposed tile
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* dst = smem + (wave * BN + c4 * 4 + e) * 3;
+                dst[0] = sg[e]; dst[1] = s0[e]; dst[2] = s1[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) { const float* s = smem + (wv * BN + tid) * 3; a0 += s[0]; a1 += s[1]; a2 += s[2]; }
+            const size_t prow = (size_t)(cls * p.MT + mt) * p.Cin + n0 + tid;
+            const size_t pstride = (size_t)p.eP * p.Cin;
+            p.esum[prow] = a0;
+            p.esum[pstride + prow] = a1;
+            if (p.ey1) p.esum[2 * pstride + prow] = a2;
+        }
+    }
+}
+
 // ======================================================================================================
 // Input gradient. Stride-s convolutions are decomposed into s*s parity classes of input pixels; each
 // class only visits the filter taps that can reach it, so no MFMA work is spent on structural zeros.
 // blockIdx.y = class. GEMM N = Cin, K = (taps of the class) x Cout.
 // ======================================================================================================
-template <int WM, int WN, int NST, bool FUSED>
+// KS: the launch carries a K-split tail (stride 1 only; see tile_of_block_split), its own instantiation like k_conv_fwd's
+template <int WM, int WN, int NST, bool FUSED, bool KS = false>
 __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0) {
+    static_assert(!KS || (WM == 1 && WN == 1 && NST == 1), "the K-split tail is built for the single-buffered 64x64 tile");
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32;
     constexpr int LDC = BN + 4;
@@ -461,8 +548,9 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
     constexpr int STAGE = BM * LDR + BK * LDC;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    int mt, nt;
-    if (!tile_of_block(blockIdx.x, p.MT, p.NT, mt, nt)) return;
+    int mt, nt, ks = -1;
+    if (KS) { if (!tile_of_block_split(p, blockIdx.x, mt, nt, ks)) return; }
+    else if (!tile_of_block(blockIdx.x, p.MT, p.NT, mt, nt)) return;
     const int st = p.stride;
     const int cls = blockIdx.y, ph = cls / st, pw = cls - ph * st;
     // class grid: pixels h = ph + st*h2 < H
@@ -524,8 +612,14 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
             for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
 
     const int KC = p.Cout / BK;          // K tiles per tap
-    const int T = nR * nS * KC;
+    const int Tall = nR * nS * KC;
+    const int t0 = (!KS || ks < 0) ? 0 : ks * p.ks_T;            // this workgroup's K tiles [t0, T)
+    const int T = (!KS || ks < 0) ? Tall : min(Tall, t0 + p.ks_T);
     int jr = 0, js = 0, c0 = 0;
+    if (KS && ks > 0) {
+        const int tap = t0 / KC;
+        c0 = (t0 - tap * KC) * BK; jr = tap / nS; js = tap - jr * nS;
+    }
     f32x4 ra[AR], rbv[BRN];
     const int bk_row = tid / BV, bk_col = (tid % BV) * 4;
 
@@ -559,12 +653,12 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
         for (int i = 0; i < BRN; ++i) *reinterpret_cast<f32x4*>(sB + (bk_row + BRP * i) * LDC + bk_col) = rbv[i];
     };
 
-    if (T > 0) {
+    if (T > t0) {
         gload(); advance();
         sstore(0);
         __syncthreads();
-        for (int t = 0; t < T; ++t) {
-            const int buf = NST == 2 ? (t & 1) : 0;
+        for (int t = t0; t < T; ++t) {
+            const int buf = NST == 2 ? ((t - t0) & 1) : 0;
             if (t + 1 < T) { gload(); advance(); }
             const float* sA = smem + buf * STAGE;
             mma_RC<WM, WN, LDC>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
@@ -585,79 +679,18 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) tile[(wm * 32 + acc_row(rr, lane)) * LDT + wn * 32 + (lane & 31)] = acc[0][0][rr];
         __syncthreads();
-        const int c4 = tid & 15, rg = tid >> 4;
-        const int col = n0 + c4 * 4;
-        f32x4 sg = {0, 0, 0, 0}, s0 = sg, s1 = sg, mu0 = sg, is0 = sg, mu1 = sg, is1 = sg, gsc = sg, gsh = sg;
-        if (FUSED && p.esum) {
-            mu0 = ld4(p.emean0 + col); is0 = ld4(p.einv0 + col);
-            if (p.ey1) { mu1 = ld4(p.emean1 + col); is1 = ld4(p.einv1 + col); }
+        if (KS && ks >= 0) {   // K split of a remainder tile: raw accumulators to the slab, the epilogue runs in k_conv_dgrad_tail_fixup
+            float* dst = p.ks_slab + ((size_t)((mt - p.MT1) * p.NT + nt) * p.ks_S + ks) * (BM * BN);
+            const int c4 = tid & 15, rg = tid >> 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rl = rg + 16 * k;
+                *reinterpret_cast<f32x4*>(dst + rl * BN + c4 * 4) = *reinterpret_cast<const f32x4*>(tile + rl * LDT + c4 * 4);
+            }
+            return;
         }
-        if (FUSED && p.escale0) { gsc = ld4(p.escale0 + col); gsh = ld4(p.eshift0 + col); }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int rl = rg + 16 * k;
-            const int m = m0 + rl;
-            if (m >= Mc) continue;
-            uint32_t pix = (uint32_t)m;
-            if (st != 1) {
-                const uint32_t b = fdiv((uint32_t)m, dHW);
-                const uint32_t rem = (uint32_t)m - b * dHW.d;
-                const uint32_t h2 = fdiv(rem, dW), w2 = rem - h2 * dW.d;
-                pix = (b * p.H + (ph + st * h2)) * p.W + (pw + st * w2);
-            }
-            const uint32_t off = pix * p.Cin + col;
-            f32x4 v = *reinterpret_cast<const f32x4*>(tile + rl * LDT + c4 * 4);
-            if (p.addend) v += ld4(p.addend + off);   // may be the output buffer itself: read and written by the same lane
-            if (FUSED) {
-                if (p.ebits) {   // 1 bit / element: words (i4 >> 6) * 4 + component, bit i4 & 63 (bn.hip)
-                    const uint32_t i4 = off >> 2;
-                    const ulonglong2* wp = reinterpret_cast<const ulonglong2*>(p.ebits + (size_t)(i4 >> 6) * 4);
-                    const ulonglong2 w01 = wp[0], w23 = wp[1];
-                    const int bit = i4 & 63;
-                    v[0] = (w01.x >> bit) & 1 ? v[0] : 0.f; v[1] = (w01.y >> bit) & 1 ? v[1] : 0.f;
-                    v[2] = (w23.x >> bit) & 1 ? v[2] : 0.f; v[3] = (w23.y >> bit) & 1 ? v[3] : 0.f;
-                }
-                f32x4 y0v = {0, 0, 0, 0};
-                if (p.escale0 || p.esum) y0v = ld4(p.ey0 + off);
-                if (p.escale0) {   // the producer's activation was never stored: its ReLU gate is recomputed from the pre-BN tensor
-#pragma unroll               // with the very expression (one fma) the forward loader used
-                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(y0v[e], gsc[e], gsh[e]) > 0.f ? v[e] : 0.f;
-                }
-                if (p.esum) {    // BatchNorm-backward partial sums of the consumer(s): sum g, sum g*xhat0 [, sum g*xhat1]
-                    sg += v;
-                    s0 += (v * (y0v - mu0)) * is0;
-                    if (p.ey1) s1 += (v * (ld4(p.ey1 + off) - mu1)) * is1;
-                }
-            }
-            *reinterpret_cast<f32x4*>(p.y + off) = v;
-        }
-        if (FUSED && p.esum) {
-            // rows of one channel quad: 4 lanes of the wave (lane bits 4, 5), then the 4 waves through LDS, in wave order
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sg[e] += __shfl_xor(sg[e], 16, 64); s0[e] += __shfl_xor(s0[e], 16, 64); s1[e] += __shfl_xor(s1[e], 16, 64);
-                sg[e] += __shfl_xor(sg[e], 32, 64); s0[e] += __shfl_xor(s0[e], 32, 64); s1[e] += __shfl_xor(s1[e], 32, 64);
-            }
-            __syncthreads();   // every lane is done reading the transposed tile
-            if (lane < 16) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float* dst = smem + (wave * BN + c4 * 4 + e) * 3;
-                    dst[0] = sg[e]; dst[1] = s0[e]; dst[2] = s1[e];
-                }
-            }
-            __syncthreads();
-            if (tid < BN) {
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < 4; ++wv) { const float* s = smem + (wv * BN + tid) * 3; a0 += s[0]; a1 += s[1]; a2 += s[2]; }
-                const size_t prow = (size_t)(cls * p.MT + mt) * p.Cin + n0 + tid;
-                const size_t pstride = (size_t)p.eP * p.Cin;
-                p.esum[prow] = a0;
-                p.esum[pstride + prow] = a1;
-                if (p.ey1) p.esum[2 * pstride + prow] = a2;
-            }
-        }
+        dgrad_epilogue64<FUSED>(p, smem, cls, mt, m0, n0, Mc, st, ph, pw, dHW, dW,
+                                [&](int rl, int c4) { return *reinterpret_cast<const f32x4*>(tile + rl * LDT + c4 * 4); });
         return;
     }
 
@@ -1166,6 +1199,22 @@ __global__ __launch_bounds__(256) void k_conv_fwd_tail_fixup(ConvP p) {
     }
 }
 
+// Fix-up pass of an input-gradient launch with a K-split tail (stride 1): per remainder tile, the splits are added in split order
+// and the tile goes through the very epilogue of the convolution kernel (dgrad_epilogue64).
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_conv_dgrad_tail_fixup(ConvP p) {
+    __shared__ float red[4 * 64 * 3];
+    const int tile = blockIdx.x;
+    const int mt = p.MT1 + tile / p.NT, nt = tile - (tile / p.NT) * p.NT;
+    const float* src = p.ks_slab + (size_t)tile * p.ks_S * 4096;
+    const int nsp = p.ks_S;
+    dgrad_epilogue64<FUSED>(p, red, 0, mt, mt * 64, nt * 64, p.B * p.H * p.W, 1, 0, 0, p.cHW[0], p.cW[0], [&](int rl, int c4) {
+        f32x4 a = ld4(src + rl * 64 + c4 * 4);
+        for (int sp = 1; sp < nsp; ++sp) a += ld4(src + (size_t)sp * 4096 + rl * 64 + c4 * 4);
+        return a;
+    });
+}
+
 // out[i] = sum_s slab[s][i]  (fixed order: bitwise reproducible)
 // One workgroup = 16 consecutive float4 outputs x 16 split lanes: lane j sums splits j, j+16, ... (4 independent loads in
 // flight), then the 16 lane partials are added in lane order. Many small dependent-latency chains instead of one long one.
@@ -1254,15 +1303,17 @@ static int chip_cus() {
     return n;
 }
 struct TailPlan { int MT1, S, ksT, tiles; };   // tiles = remainder tiles ((MT - MT1) * NT); S <= 1: no split
-// MT x NT tiles of 64x64, T K-tiles each. Splits the ragged last round when that buys at least ~4 % of the launch (the fix-up pass
-// and its launch boundary cost a few microseconds) and every split keeps at least 2 K tiles.
+// MT x NT tiles of 64x64, T K-tiles each. Splits the ragged last round when the model says it buys at least 8 % of the launch and
+// every split keeps at least 2 K tiles. Measured (tools/bench_tail.py, B = 128): 3 rounds + 16 tiles (7x7 layers) +15 %, 6 rounds +
+// 32 tiles (14x14, 256 channels) +7.5 %, 12 rounds + 64 tiles (a 5.8 % model gain) -1.5 ... -3.6 %: the fix-up pass and its launch
+// boundary cost what the balance returns, so those launches stay single-pass.
 static TailPlan plan_tail_split(long MT, int NT, int T) {
     TailPlan t{(int)MT, 1, T, 0};
     if (!g_osi_tuning.tail_split || T < 4) return t;
     const long ncu = chip_cus(), V = MT * NT;
     const long q = V / ncu, r = V - q * ncu;
-    if (r == 0 || q > 13) return t;
-    if ((double)(ncu - r) / (double)ncu / (double)(q + 1) < 0.04) return t;
+    if (r == 0 || q > 8) return t;
+    if ((double)(ncu - r) / (double)ncu / (double)(q + 1) < 0.08) return t;
     long MT1 = q * ncu / NT;                       // full rounds, in whole row tiles
     long rem = (MT - MT1) * NT;
     long S = ncu / rem;
@@ -1327,6 +1378,24 @@ static int launch_dgrad_impl(ConvP p, hipStream_t st) {
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
+// 64x64 single-buffered input gradient with a K-split tail (stride 1): convolution launch + fix-up pass
+template <bool FUSED>
+static int launch_dgrad_split(ConvP p, const TailPlan& tp, float* slab, hipStream_t st) {
+    p.cHW[0] = make_fastdiv((uint32_t)(p.H * p.W)); p.cW[0] = make_fastdiv((uint32_t)p.W);
+    p.unit = (p.R == 1 && p.S == 1 && p.pad == 0) ? 1 : 0;
+    p.MT = osi_cdiv((long)p.B * p.H * p.W, 64); p.NT = p.Cin / 64;
+    p.MT1 = tp.MT1; p.ks_S = tp.S; p.ks_T = tp.ksT; p.ks_slab = slab;
+    p.g1 = osi_cdiv(p.MT1, 8) * 8 * p.NT;
+    const int keys = (p.MT - p.MT1) * tp.S;
+    const int grid = p.g1 + osi_cdiv(keys, 8) * 8 * p.NT;
+    const size_t smem = (size_t)(64 * LDR + BK * (64 + 4)) * sizeof(float);
+    hipLaunchKernelGGL((k_conv_dgrad<1, 1, 1, FUSED, true>), dim3(grid, 1), dim3(256), smem, st, p, p.H, p.W);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_conv_dgrad_tail_fixup<FUSED>, dim3(tp.tiles), dim3(256), 0, st, p);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
 template <int WM, int WN, int NST = 2>
 static int launch_dgrad(ConvP p, hipStream_t st) {
     // the fused epilogue (mask / BatchNorm reductions) is its own instantiation so that plain launches keep the small one
@@ -1583,11 +1652,21 @@ int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, floa
     return conv_dgrad_impl(d, dy, w, dx, accumulate ? dx : nullptr, nullptr, tile, nullptr, stream);
 }
 
-size_t osi_conv_dgrad_fused_workspace(const osi_conv_desc* d) {
-    if (!desc_ok(d)) return 0;
+// floats of the partial-sum part of the fused input-gradient workspace, rounded to 256 B: the slab of a K-split tail starts behind it
+static size_t dgrad_partial_floats(const osi_conv_desc* d) {
     const int s = d->stride;
     const long mt = osi_cdiv((long)d->B * osi_cdiv(d->H, s) * osi_cdiv(d->W, s), 64);
-    return (size_t)3 * s * s * mt * d->Cin * sizeof(float);
+    return ((size_t)3 * s * s * mt * d->Cin + 63) / 64 * 64;
+}
+static TailPlan dgrad_tail_plan(const osi_conv_desc* d) {
+    const long M = (long)d->B * d->H * d->W;
+    if (d->stride != 1 || is_stem(d) || d->Cin % 64 || d->Cout % BK) return TailPlan{(int)osi_cdiv(M, 64), 1, 0, 0};
+    return plan_tail_split(osi_cdiv(M, 64), d->Cin / 64, d->R * d->S * d->Cout / BK);
+}
+
+size_t osi_conv_dgrad_fused_workspace(const osi_conv_desc* d) {
+    if (!desc_ok(d)) return 0;
+    return (dgrad_partial_floats(d) + tail_slab_floats(dgrad_tail_plan(d))) * sizeof(float);
 }
 
 int osi_conv_dgrad_fused(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,
@@ -1624,6 +1703,10 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
             OSI_REQUIRE(f->partials_bytes >= (size_t)3 * p.eP * d->Cin * sizeof(float));
             p.ey0 = f->y0; p.ey1 = f->y1; p.esum = f->partials;
             *P = p.eP;
+            // ragged last round split along K when the caller's workspace has room for the slab behind the partial sums
+            const TailPlan tp = dgrad_tail_plan(d);
+            if (tile == OSI_TILE_64x64_S1 && tp.S > 1 && f->partials_bytes >= (dgrad_partial_floats(d) + tail_slab_floats(tp)) * sizeof(float))
+                return launch_dgrad_split<true>(p, tp, f->partials + dgrad_partial_floats(d), st);
         }
     }
     switch (tile) {

@@ -55,7 +55,10 @@ def test_conv_fwd_with_fused_input_activation(cuda, Cin, Cout, k, stride, H, B, 
     # without statistics, and the materialised-activation route through the plain kernel agrees to summation-order noise
     y2 = torch.empty_like(y)
     N.check(L.osi_conv_fwd_act(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(w), N.ptr(y2), tile, None, 0, None, None, T.S()))
-    assert torch.equal(y2, y)
+    if tile == 0:   # AUTO + statistics may split the ragged last round along K; without a workspace it cannot
+        assert float((y2 - y).abs().max()) <= 1e-5 * float(ref.abs().max())
+    else:
+        assert torch.equal(y2, y)
     act32 = torch.relu(torch.addcmul(sh, x, sc)).contiguous()
     y3 = T.conv_fwd(act32, w, k, stride, pad, tile)
     assert float((y3 - y).abs().max()) <= 1e-5 * float(ref.abs().max())
