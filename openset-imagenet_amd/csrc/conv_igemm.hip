@@ -445,6 +445,139 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     }
 }
 
+// ======================================================================================================
+// Stem forward, direct form: 7x7 / stride 2 / pad 3 convolution of a 3-channel image (Cout = 64).
+// The implicit-GEMM kernel above spends 224 K slots on 147 real taps (4th channel + 7 padded taps: 34 % of its MFMAs multiply zeros)
+// and re-derives the tap geometry of every gathered float4. With only 3 input channels the whole receptive field of an output
+// tile is small: a workgroup owns 8 x 16 output pixels, stages their 21 x 37 x 3 input patch (9.3 KB) and the complete weight
+// matrix W^T[148][64] (37 KB, staged once per workgroup and reused for `tiles_per_wg` tiles) in LDS, and then runs 74 K steps of
+// v_mfma_f32_32x32x2_f32 whose A operand is a strided ds_read_b32 gather straight out of the patch (per-lane pixel base + a
+// compile-time tap offset) and whose B operand is a row of W^T: no global loads, no barriers and no address arithmetic inside the
+// K loop, K = 148 instead of 224. Same exact-fp32 FMA chains, another summation order than the implicit-GEMM form.
+// The BatchNorm partials are one (mean, M2) pair per tile of 128 pixels, the contract osi_bn_finalize_stats expects with
+// rows_per_block = 128 (every tile is full: the launcher only takes this path when Ho % 8 == 0 and Wo % 16 == 0).
+// ======================================================================================================
+constexpr int SD_TH = 8, SD_TW = 16, SD_PH = 2 * SD_TH + 5, SD_PW = 2 * SD_TW + 5, SD_K = 148;
+__host__ __device__ constexpr int sd_off(int k) {          // patch offset (floats) of tap index k = (r * 7 + s) * 3 + c
+    const int kk = k < 147 ? k : 146;                       // K padding: any valid address, its weight row is zero
+    return (kk / 21) * SD_PW * 3 + kk % 21;
+}
+__global__ __launch_bounds__(256, 3) void k_stem_fwd_direct(const float* __restrict__ x4, const float* __restrict__ wpacked,
+                                                           float* __restrict__ y, float* __restrict__ pmean, float* __restrict__ pm2,
+                                                           int B, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y, int ntiles,
+                                                           int tiles_per_wg) {
+    __shared__ float sW[SD_K * 64];
+    __shared__ float sP[SD_PH * SD_PW * 3 + 1];
+    __shared__ float sS[2 * 64 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+    // W^T[k][cout] from the packed [64][56 taps][4] weights: lanes walk the couts (conflict-free LDS stores)
+    for (int i = tid; i < 64 * 50; i += 256) {
+        const int cout = i & 63, tap = i >> 6;              // taps 49 holds the zero row k = 147 (tap 49, c = 0)
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tap < 49) v = ld4(wpacked + cout * 224 + tap * 4);
+        if (tap < 49) { sW[(tap * 3) * 64 + cout] = v[0]; sW[(tap * 3 + 1) * 64 + cout] = v[1]; sW[(tap * 3 + 2) * 64 + cout] = v[2]; }
+        else sW[147 * 64 + cout] = 0.f;
+    }
+    // A operand address of K step ks = pixel base + sd_off(2 ks) + h * (sd_off(2 ks + 1) - sd_off(2 ks)); the difference is 1 inside a
+    // patch row, SD_PW * 3 - 20 across a row wrap and 0 on the padded last step: three per-lane bases, every step's tap offset is an
+    // immediate of its ds_read (nothing per step for the compiler to precompute and spill)
+    const float* pA[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pix = wm * 64 + i * 32 + l31, py = pix >> 4, px = pix & 15;
+        const int base = (2 * py * SD_PW + 2 * px) * 3;
+        pA[i][0] = sP + base; pA[i][1] = sP + base + h; pA[i][2] = sP + base + h * (SD_PW * 3 - 20);
+    }
+    const float* pB = sW + wn * 32 + l31 + h * 64;
+    const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tiles_per_wg);
+    for (int tile = blockIdx.x * tiles_per_wg; tile < tile_end; ++tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int oy0 = ty * SD_TH, ox0 = tx * SD_TW, iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+        __syncthreads();                                    // every wave is done with the previous tile's patch (and sW is complete)
+        for (int i = tid; i < SD_PH * SD_PW; i += 256) {
+            const int py = i / SD_PW, px = i - py * SD_PW, iy = iy0 + py, ix = ix0 + px;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x4 + (((size_t)b * H + iy) * W + ix) * 4);
+            sP[i * 3] = v[0]; sP[i * 3 + 1] = v[1]; sP[i * 3 + 2] = v[2];
+        }
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // 74 K steps in groups of SD_G, software-pipelined by hand: the LDS reads of group g + 1 are issued before the MFMAs of group g
+        // (two register sets); the scheduling barriers keep the compiler from hoisting every read of the tile to the top (it does,
+        // and spills the accumulators) or sinking them next to their MFMA (exposing the LDS latency 74 times).
+        constexpr int SD_G = 4, SD_NG = (SD_K / 2 + SD_G - 1) / SD_G;
+        float ca0[SD_G], ca1[SD_G], cb[SD_G];
+        auto lds_group = [&](int g, float (&a0)[SD_G], float (&a1)[SD_G], float (&bv)[SD_G]) {
+#pragma unroll
+            for (int j = 0; j < SD_G; ++j) {
+                const int ks = g * SD_G + j;
+                if (ks < SD_K / 2) {
+                    const int o0 = sd_off(2 * ks), dl = sd_off(2 * ks + 1) - o0;
+                    const int sel = dl == 1 ? 1 : (dl == 0 ? 0 : 2);
+                    a0[j] = pA[0][sel][o0]; a1[j] = pA[1][sel][o0];
+                    bv[j] = pB[ks * 128];
+                }
+            }
+        };
+        lds_group(0, ca0, ca1, cb);
+#pragma unroll
+        for (int g = 0; g < SD_NG; ++g) {
+            float na0[SD_G], na1[SD_G], nb[SD_G];
+            if (g + 1 < SD_NG) lds_group(g + 1, na0, na1, nb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < SD_G; ++j) {
+                if (g * SD_G + j < SD_K / 2) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[j], cb[j], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[j], cb[j], acc[1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < SD_NG) {
+#pragma unroll
+                for (int j = 0; j < SD_G; ++j) { ca0[j] = na0[j]; ca1[j] = na1[j]; cb[j] = nb[j]; }
+            }
+        }
+        // output: 32 lanes of a half-wave write 128 contiguous bytes of one pixel
+        const int col = wn * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int pix = wm * 64 + i * 32 + acc_row(rr, lane);
+                y[(((size_t)b * Ho + oy0 + (pix >> 4)) * Wo + ox0 + (pix & 15)) * 64 + col] = acc[i][rr];
+            }
+        if (pmean) {   // (mean, M2) of the tile's 128 pixels per channel: this wave's 64 rows, then the two wave rows merged
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) s += acc[i][rr];
+            s += __shfl_xor(s, 32, 64);
+            const float mu = s * (1.f / 64.f);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) { const float dlt = acc[i][rr] - mu; q += dlt * dlt; }
+            q += __shfl_xor(q, 32, 64);
+            if (lane < 32) { sS[(wm * 64 + col) * 2] = mu; sS[(wm * 64 + col) * 2 + 1] = q; }
+            __syncthreads();
+            if (tid < 64) {
+                float cn = 64.f, cm = sS[tid * 2], cs = sS[tid * 2 + 1];
+                chan_merge(cn, cm, cs, 64.f, sS[(64 + tid) * 2], sS[(64 + tid) * 2 + 1]);
+                pmean[(size_t)tile * 64 + tid] = cm;
+                pm2[(size_t)tile * 64 + tid] = cs;
+            }
+        }
+    }
+}
+
 // Epilogue of one 64x64 input-gradient tile, every lane owning 4 consecutive channels of a pixel (16-byte accesses): skip-connection
 // addend, ReLU gate (stored bitmask or recomputed from the producer's pre-BN tensor), output, and the per-row-tile BatchNorm-backward
 // partial sums of the consumer layer(s). `rd(row, c4)` returns the accumulated float4 of tile row `row`, channel quad `c4`: the
@@ -1594,6 +1727,22 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
     };
     if (is_stem(d)) {
         OSI_REQUIRE(d->Cout % 64 == 0 && d->stride >= 1);
+        if (g_osi_tuning.stem_direct && tile == OSI_TILE_AUTO && d->Cout == 64 && d->stride == 2 && d->pad == 3 && d->Ho % SD_TH == 0 &&
+            d->Wo % SD_TW == 0) {
+            // direct form (k_stem_fwd_direct): full 8 x 16 output tiles only, one BatchNorm partial per tile of 128 pixels
+            const int tiles_x = d->Wo / SD_TW, tiles_y = d->Ho / SD_TH, ntiles = d->B * tiles_x * tiles_y;
+            float *pm = nullptr, *pq = nullptr;
+            if (pstats) {
+                if (pstats_bytes < (size_t)2 * ntiles * 64 * sizeof(float)) return OSI_ERR_ARG;
+                pm = pstats; pq = pstats + (size_t)ntiles * 64;
+                *P = ntiles; *rows_per_block = SD_TH * SD_TW;
+            }
+            const int per = 7;      // tiles per workgroup: the weight matrix is staged once per workgroup
+            hipLaunchKernelGGL(k_stem_fwd_direct, dim3(osi_cdiv(ntiles, per)), dim3(256), 0, st, x, w, y, pm, pq, d->B, d->H, d->W, d->Ho,
+                               d->Wo, tiles_x, tiles_y, ntiles, per);
+            OSI_LAUNCH_CHECK();
+            return OSI_OK;
+        }
         if (int e = with_stats(128)) return e;
         return launch_fwd<2, 1, true>(p, st);
     }

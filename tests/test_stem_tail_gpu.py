@@ -50,3 +50,59 @@ def test_bn_relu_maxpool_fused_equals_composition(cuda, B, H, W, C):
                                       N.ptr(db), B, H, W, C, N.ptr(ws), wsb, T.S()))
     assert torch.equal(db, db_ref) and torch.equal(dg, dg_ref)
     assert torch.equal(dy, dy_ref)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 96, 128), (2, 224, 224), (5, 32, 96)])
+def test_stem_direct_forward(cuda, B, H, W):
+    """The direct form of the stem convolution (k_stem_fwd_direct: 8 x 16 output tiles, input patch + whole weight matrix in LDS,
+    K = 148 instead of 224) against torch conv2d in fp64, against the implicit-GEMM form it replaces (same products, another
+    summation order), with its per-tile BatchNorm partials finalised by osi_bn_finalize_stats; bitwise reproducible."""
+    import ctypes
+    import torch.nn.functional as F
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(B + H + W)
+    x = torch.rand(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    y64 = F.conv2d(x.double(), w.double(), None, 2, 3)
+    x4 = torch.zeros(B, H, W, 4, device=cuda)
+    x4[..., :3] = x.permute(0, 2, 3, 1).to(cuda)
+    wp = torch.empty(64, 224, device=cuda)
+    N.check(L.osi_stem_weight_pack(N.ptr(T.krsc(w).to(cuda)), N.ptr(wp), 64, T.S()))
+    d = N.ConvDesc.make(B, H, W, 4, 64, 7, 2, 3)
+    M = B * d.Ho * d.Wo
+    nb = L.osi_conv_fwd_bnstats_workspace(ctypes.byref(d))
+
+    def run():
+        ps = torch.full((nb // 4,), float("nan"), device=cuda)
+        y = torch.full((B, d.Ho, d.Wo, 64), float("nan"), device=cuda)
+        P, rows = ctypes.c_int(), ctypes.c_int()
+        N.check(L.osi_conv_fwd_bnstats(ctypes.byref(d), N.ptr(x4), N.ptr(wp), N.ptr(y), 0, N.ptr(ps), nb, ctypes.byref(P), ctypes.byref(rows), T.S()))
+        return y, ps, P.value, rows.value
+    y1, ps1, P1, rows1 = run()
+    y2, ps2, _, _ = run()
+    N.check(L.osi_set_tuning(b"stem_direct", 0))
+    try:
+        y0, _, P0, rows0 = run()
+    finally:
+        N.check(L.osi_set_tuning(b"stem_direct", 1))
+    assert (P1, rows1) == (M // 128, 128) and rows0 == 128
+    ref = y64.permute(0, 2, 3, 1)
+    tol = (2e-6 + 6e-8 * 147 ** 0.5) * float(ref.abs().max())
+    assert float((y1.cpu().double() - ref).abs().max()) <= tol and float((y0.cpu().double() - ref).abs().max()) <= tol
+    assert torch.equal(y1, y2) and torch.equal(ps1[:2 * P1 * 64], ps2[:2 * P1 * 64])
+    assert float((y1 - y0).abs().max()) <= 1e-5 * float(ref.abs().max()) and not torch.equal(y1, y0)
+    # eval-mode entry point (no statistics) runs the same kernel: same bits
+    y3 = torch.empty_like(y1)
+    N.check(L.osi_conv_fwd(ctypes.byref(d), N.ptr(x4), N.ptr(wp), N.ptr(y3), 0, T.S()))
+    assert torch.equal(y3, y1)
+    # the per-tile partials finalise to the batch statistics of this output
+    ga, be = torch.rand(64, device=cuda) + 0.5, torch.randn(64, device=cuda)
+    mean, invstd, scale, shift = (torch.empty(64, device=cuda) for _ in range(4))
+    N.check(L.osi_bn_finalize_stats(N.ptr(ps1), nb, P1, rows1, M, 64, N.ptr(ga), N.ptr(be), 1e-5, 0.1, None, None,
+                                    N.ptr(mean), N.ptr(invstd), N.ptr(scale), N.ptr(shift), T.S()))
+    yv = y1.double().view(M, 64)
+    assert float((mean.double() - yv.mean(0)).abs().max()) <= 2e-6 * float(yv.abs().max())
+    inv64 = 1 / torch.sqrt(yv.var(0, unbiased=False) + 1e-5)
+    assert float(((invstd.double() - inv64) / inv64).abs().max()) <= 2e-5
