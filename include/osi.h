@@ -107,6 +107,14 @@ int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, floa
 int osi_conv_wgrad_act(const osi_conv_desc* d, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
                        void* ws, size_t ws_bytes, osi_stream_t stream);
 int osi_stem_weight_pack(const float* w_krsc3, float* w_packed, int Cout, osi_stream_t stream);
+/* Direct form of the stem weight gradient (7x7 / stride 2 / pad 3, Cout = 64, Ho % 8 == 0, Wo % 16 == 0 — the conv1 of
+ * torchvision's resnet50 under model.py:17 at any image size that is a multiple of 16 x 32): writes the gradient in the PARAMETER
+ * layout [64][7][7][3] directly (no packed form, no unpack pass), deterministic (one partial per workgroup, fixed-order reduce).
+ * osi_stem_wgrad_direct_workspace returns 0 for a geometry it does not take (use osi_conv_wgrad + osi_stem_grad_unpack then);
+ * osi_stem_wgrad_direct returns OSI_ERR_ARG for it. x4 = the NHWC4 image the forward read. */
+size_t osi_stem_wgrad_direct_workspace(const osi_conv_desc* d);
+int osi_stem_wgrad_direct(const osi_conv_desc* d, const float* dy, const float* x4, float* dw_krsc3, void* ws, size_t ws_bytes,
+                          osi_stream_t stream);
 int osi_stem_grad_unpack(const float* g_packed, float* g_krsc3, int Cout, osi_stream_t stream);
 
 /* ---- BatchNorm2d in training mode + ReLU + residual (torchvision Bottleneck under model.py:37; train() at train.py:125) --- */

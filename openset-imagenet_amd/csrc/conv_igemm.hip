@@ -85,6 +85,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int 
 __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ f32x3 bld3(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0));
+}
 
 // XCD-aware tile mapping: workgroups b and b+8 share an XCD (and its L2). All NT column tiles of one row
 // tile are placed on one XCD in consecutive dispatch slots, so the im2col rows are fetched from HBM once.
@@ -491,17 +495,48 @@ __global__ __launch_bounds__(256, 3) void k_stem_fwd_direct(const float* __restr
     }
     const float* pB = sW + wn * 32 + l31 + h * 64;
     const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tiles_per_wg);
+    // input patch of a tile: branch-free buffer loads into registers (out-of-image pixels: sentinel offset -> zeros = the padding);
+    // the NEXT tile's loads are issued before the K loop and stored to LDS behind it
+    constexpr int NPX = (SD_PH * SD_PW + 255) / 256;
+    const __amdgpu_buffer_rsrc_t rxb = make_rsrc(x4, (int)((size_t)B * H * W * 16));
+    f32x3 rpx[NPX];      // 12-byte loads (see k_stem_wgrad_direct)
+    uint32_t prel[NPX];
+    int ppy[NPX], ppx[NPX];
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+        const int i = tid + j * 256;
+        ppy[j] = i / SD_PW; ppx[j] = i - ppy[j] * SD_PW;
+        prel[j] = (uint32_t)((ppy[j] * W + ppx[j]) * 16);
+        if (i >= SD_PH * SD_PW) ppy[j] = 1 << 20;          // never inside the image
+    }
+    auto gload = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int iy0 = 2 * ty * SD_TH - 3, ix0 = 2 * tx * SD_TW - 3;
+        const int pbase = __builtin_amdgcn_readfirstlane(((b * H + iy0) * W + ix0) * 16);   // may be negative at the image border: only used where the pixel is valid
+        uint32_t poff[NPX];
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const int ok = ((unsigned)(iy0 + ppy[j]) < (unsigned)H) & ((unsigned)(ix0 + ppx[j]) < (unsigned)W);
+            poff[j] = ok ? (uint32_t)(pbase + (int)prel[j]) : OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) rpx[j] = bld3(rxb, poff[j], 0);
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const int i = tid + j * 256;
+            if (i < SD_PH * SD_PW) { sP[i * 3] = rpx[j][0]; sP[i * 3 + 1] = rpx[j][1]; sP[i * 3 + 2] = rpx[j][2]; }
+        }
+    };
+    if ((int)blockIdx.x * tiles_per_wg < tile_end) gload(blockIdx.x * tiles_per_wg);
     for (int tile = blockIdx.x * tiles_per_wg; tile < tile_end; ++tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-        const int oy0 = ty * SD_TH, ox0 = tx * SD_TW, iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+        const int oy0 = ty * SD_TH, ox0 = tx * SD_TW;
         __syncthreads();                                    // every wave is done with the previous tile's patch (and sW is complete)
-        for (int i = tid; i < SD_PH * SD_PW; i += 256) {
-            const int py = i / SD_PW, px = i - py * SD_PW, iy = iy0 + py, ix = ix0 + px;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x4 + (((size_t)b * H + iy) * W + ix) * 4);
-            sP[i * 3] = v[0]; sP[i * 3 + 1] = v[1]; sP[i * 3 + 2] = v[2];
-        }
+        sstore();
         __syncthreads();
+        if (tile + 1 < tile_end) gload(tile + 1);
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -575,6 +610,135 @@ __global__ __launch_bounds__(256, 3) void k_stem_fwd_direct(const float* __restr
                 pm2[(size_t)tile * 64 + tid] = cs;
             }
         }
+    }
+}
+
+// ======================================================================================================
+// Stem weight gradient, direct form: dW[cout][k] = sum over pixels dY[pix][cout] * patch(pix)[k], k = (r * 7 + s) * 3 + c.
+// The implicit-GEMM kernel walks K = pixels with a 224-wide padded tap axis (147 real columns) and streams dY once per column tile
+// (4x). Here a workgroup of five waves owns the whole 64 x 160 gradient tile in registers (wave w = tap columns 32 w .. 32 w + 31,
+// both 32-cout row tiles), loops over its share of 8 x 16-pixel output tiles, and per tile stages the dY rows (32 KB, a straight
+// copy: the tile's rows are contiguous in NHWC) and the 21 x 37 x 3 input patch in LDS. K step = 2 pixels: A = dY[pix][cout] (conflict-
+// free), B = patch[base(pix) + tap offset of the lane's column] with the pixel base an immediate — as in k_stem_fwd_direct there is no
+// address arithmetic, no global load and no barrier inside the 64 K steps of a tile; the next tile's global loads are issued before
+// them and land in LDS after. Each workgroup writes ONE partial [64][147] slab; k_slab_reduce adds them in workgroup order (fixed,
+// bitwise reproducible) straight into the parameter-layout gradient [64][7][7][3] (no packed intermediate, no unpack pass).
+// ======================================================================================================
+constexpr int SDW_THREADS = 320;
+__global__ __launch_bounds__(SDW_THREADS, 2) void k_stem_wgrad_direct(const float* __restrict__ dy, const float* __restrict__ x4,
+                                                                    float* __restrict__ slab, int B, int H, int W, int Ho, int Wo,
+                                                                    int tiles_x, int tiles_y, int ntiles, int tiles_per_wg) {
+    __shared__ __attribute__((aligned(16))) float sDY[128 * 64];
+    __shared__ float sP[SD_PH * SD_PW * 3 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid / 64;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int kcol = wave * 32 + l31;                      // this lane's tap column (>= 147: padding, never stored)
+    const float* pA = sDY + l31 + h * 64;
+    const float* pB = sP + sd_off(kcol) + h * 6;           // pixel 2 ks + 1 is the right-hand neighbour of pixel 2 ks: + 2 input pixels
+    constexpr int NDY = (128 * 16 + SDW_THREADS - 1) / SDW_THREADS;      // float4 per thread of a dY tile (7)
+    constexpr int NPX = (SD_PH * SD_PW + SDW_THREADS - 1) / SDW_THREADS; // patch pixels per thread (3)
+    f32x4 rdy[NDY];
+    f32x3 rpx[NPX];      // 12-byte loads: the 4th channel of the NHWC4 image is padding, and a dead 4th register would be reused by the
+                         // allocator while the load is in flight (a vmcnt wait in front of the K loop)
+    // Branch-free loads (buffer descriptors, sentinel offset -> zeros): with conditional loads the compiler has to drain vmcnt at every
+    // control-flow merge, i.e. BEFORE the K loop, and the prefetch of the next tile is exposed instead of hidden behind 128 MFMAs.
+    const __amdgpu_buffer_rsrc_t rdyb = make_rsrc(dy, (int)((size_t)B * Ho * Wo * 64 * 4)), rxb = make_rsrc(x4, (int)((size_t)B * H * W * 16));
+    // per-thread offsets relative to the tile origin, computed once: the per-tile part is scalar
+    uint32_t drel[NDY], prel[NPX];
+    int ppy[NPX], ppx[NPX];
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) {
+        const int f = tid + j * SDW_THREADS;               // float4 index inside the tile: row py = f / 256, then 16 pixels x 16 float4
+        drel[j] = f < 128 * 16 ? (uint32_t)((((f >> 8) * Wo) * 64 + (f & 255) * 4) * 4) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+        const int i = tid + j * SDW_THREADS;
+        ppy[j] = i / SD_PW; ppx[j] = i - ppy[j] * SD_PW;
+        prel[j] = (uint32_t)((ppy[j] * W + ppx[j]) * 16);
+        if (i >= SD_PH * SD_PW) ppy[j] = 1 << 20;          // never inside the image
+    }
+    auto gload = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int oy0 = ty * SD_TH, ox0 = tx * SD_TW, iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+        // wave-uniform by construction (functions of the tile index); said explicitly, or hipcc wraps every load that takes the scalar
+        // offset in a waterfall loop
+        const uint32_t dbase = (uint32_t)__builtin_amdgcn_readfirstlane(((b * Ho + oy0) * Wo + ox0) * 64 * 4);
+        const int pbase = __builtin_amdgcn_readfirstlane(((b * H + iy0) * W + ix0) * 16);   // may be negative at the image border: only used where the pixel is valid
+        uint32_t poff[NPX];
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const int ok = ((unsigned)(iy0 + ppy[j]) < (unsigned)H) & ((unsigned)(ix0 + ppx[j]) < (unsigned)W);
+            poff[j] = ok ? (uint32_t)(pbase + (int)prel[j]) : OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < NDY; ++j) rdy[j] = bld4(rdyb, drel[j], dbase);   // a sentinel offset stays out of range with the scalar base added
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) rpx[j] = bld3(rxb, poff[j], 0);
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NDY; ++j) {
+            const int f = tid + j * SDW_THREADS;
+            if (f < 128 * 16) *reinterpret_cast<f32x4*>(sDY + f * 4) = rdy[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const int i = tid + j * SDW_THREADS;
+            if (i < SD_PH * SD_PW) { sP[i * 3] = rpx[j][0]; sP[i * 3 + 1] = rpx[j][1]; sP[i * 3 + 2] = rpx[j][2]; }
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int tile0 = blockIdx.x * tiles_per_wg, tile_end = min(ntiles, tile0 + tiles_per_wg);
+    if (tile0 < tile_end) {
+        gload(tile0);
+        sstore();
+        __syncthreads();
+        for (int tile = tile0; tile < tile_end; ++tile) {
+            if (tile + 1 < tile_end) gload(tile + 1);
+            // 64 K steps (2 pixels each) in groups of 4, LDS reads of group g + 1 issued before the MFMAs of group g (see k_stem_fwd_direct)
+            constexpr int G = 4, NG = 64 / G;
+            float ca0[G], ca1[G], cb[G];
+            auto lds_group = [&](int g, float (&a0)[G], float (&a1)[G], float (&bv)[G]) {
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int ks = g * G + j, pix = 2 * ks;
+                    a0[j] = pA[ks * 128]; a1[j] = pA[ks * 128 + 32];
+                    bv[j] = pB[(2 * (pix >> 4) * SD_PW + 2 * (pix & 15)) * 3];
+                }
+            };
+            lds_group(0, ca0, ca1, cb);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float na0[G], na1[G], nb[G];
+                if (g + 1 < NG) lds_group(g + 1, na0, na1, nb);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[j], cb[j], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[j], cb[j], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j) { ca0[j] = na0[j]; ca1[j] = na1[j]; cb[j] = nb[j]; }
+                }
+            }
+            __syncthreads();                                // every wave is done reading this tile
+            if (tile + 1 < tile_end) { sstore(); __syncthreads(); }
+        }
+    }
+    // partial gradient of this workgroup: rows = cout (accumulator rows), column = this lane's tap index
+    if (kcol < 147) {
+        float* out = slab + (size_t)blockIdx.x * (64 * 147);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) out[(i * 32 + acc_row(rr, lane)) * 147 + kcol] = acc[i][rr];
     }
 }
 
@@ -1942,6 +2106,42 @@ static int conv_wgrad_impl(const osi_conv_desc* d, const float* dy, const float*
         hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)ws, dw, n4, n4, w.splits);
         OSI_LAUNCH_CHECK();
     }
+    return OSI_OK;
+}
+
+// direct stem weight gradient: geometry it takes, split plan, workspace
+static bool stem_wgrad_direct_ok(const osi_conv_desc* d) {
+    return g_osi_tuning.stem_direct && desc_ok(d) && is_stem(d) && d->Cout == 64 && d->stride == 2 && d->pad == 3 && d->Ho % SD_TH == 0 &&
+           d->Wo % SD_TW == 0;
+}
+static void stem_wgrad_plan(const osi_conv_desc* d, int& ntiles, int& per, int& groups) {
+    ntiles = d->B * (d->Ho / SD_TH) * (d->Wo / SD_TW);
+    // persistent workgroups, three per CU (41 KB of LDS each): one partial slab per workgroup
+    const int want = 3 * chip_cus();
+    per = osi_cdiv(ntiles, want);
+    if (per < 1) per = 1;
+    groups = osi_cdiv(ntiles, per);
+}
+size_t osi_stem_wgrad_direct_workspace(const osi_conv_desc* d) {
+    if (!d || !stem_wgrad_direct_ok(d)) return 0;
+    int ntiles, per, groups;
+    stem_wgrad_plan(d, ntiles, per, groups);
+    return (size_t)groups * 64 * 147 * sizeof(float);
+}
+int osi_stem_wgrad_direct(const osi_conv_desc* d, const float* dy, const float* x4, float* dw_krsc3, void* ws, size_t ws_bytes,
+                          osi_stream_t stream) {
+    OSI_REQUIRE(d && dy && x4 && dw_krsc3 && ws);
+    if (!stem_wgrad_direct_ok(d)) return OSI_ERR_ARG;
+    int ntiles, per, groups;
+    stem_wgrad_plan(d, ntiles, per, groups);
+    OSI_REQUIRE(ws_bytes >= (size_t)groups * 64 * 147 * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_stem_wgrad_direct, dim3(groups), dim3(SDW_THREADS), 0, st, dy, x4, (float*)ws, d->B, d->H, d->W, d->Ho, d->Wo,
+                       d->Wo / SD_TW, d->Ho / SD_TH, ntiles, per);
+    OSI_LAUNCH_CHECK();
+    const size_t n4 = 64 * 147 / 4;
+    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)ws, dw_krsc3, n4, n4, groups);
+    OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
 

@@ -275,6 +275,8 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
         if (b3 > bnws) bnws = b3;
         size_t wg = osi_conv_wgrad_workspace(&c.d);
         if (wg > wgws) wgws = wg;
+        wg = osi_stem_wgrad_direct_workspace(&c.d);
+        if (wg > wgws) wgws = wg;
         if (!(c.d.Cin == 4 && c.d.R == 7)) { size_t dg = osi_conv_dgrad_fused_workspace(&c.d); if (dg > dgws) dgws = dg; }
     }
     n->bn_ws_bytes = bnws; n->bn_ws = n->ws_alloc(bnws / 4 + 4); n->bn_ws2 = n->ws_alloc(bnws / 4 + 4);
@@ -533,8 +535,12 @@ static int wgrad_launch(osi_resnet50* n, int ci, float* grads, float* ws, int gi
         ws_st = n->side;
     }
     if (ci == 0) {
-        OSI_TRY(osi_conv_wgrad(&c.d, dy, conv_in, ws + n->gpack, ws + n->wg_ws, n->wg_ws_bytes, ws_st));
-        OSI_TRY(osi_stem_grad_unpack(ws + n->gpack, grads + c.w_off, 64, ws_st));
+        if (osi_stem_wgrad_direct_workspace(&c.d) > 0) {      // direct form: the parameter-layout gradient in one go
+            OSI_TRY(osi_stem_wgrad_direct(&c.d, dy, conv_in, grads + c.w_off, ws + n->wg_ws, n->wg_ws_bytes, ws_st));
+        } else {
+            OSI_TRY(osi_conv_wgrad(&c.d, dy, conv_in, ws + n->gpack, ws + n->wg_ws, n->wg_ws_bytes, ws_st));
+            OSI_TRY(osi_stem_grad_unpack(ws + n->gpack, grads + c.w_off, 64, ws_st));
+        }
     } else if (in_bn >= 0) {
         OSI_TRY(osi_conv_wgrad_act(&c.d, dy, conv_in, ws + n->bns[in_bn].scale, ws + n->bns[in_bn].shift, grads + c.w_off, ws + n->wg_ws,
                                    n->wg_ws_bytes, ws_st));

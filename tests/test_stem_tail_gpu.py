@@ -106,3 +106,42 @@ def test_stem_direct_forward(cuda, B, H, W):
     assert float((mean.double() - yv.mean(0)).abs().max()) <= 2e-6 * float(yv.abs().max())
     inv64 = 1 / torch.sqrt(yv.var(0, unbiased=False) + 1e-5)
     assert float(((invstd.double() - inv64) / inv64).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 96, 128), (4, 224, 224), (5, 32, 96)])
+def test_stem_direct_weight_gradient(cuda, B, H, W):
+    """Direct stem weight gradient (k_stem_wgrad_direct: the whole 64 x 147 gradient in the registers of a five-wave workgroup,
+    dY rows + input patch staged per 8 x 16 tile, one partial per workgroup) against torch conv2d_weight in fp64 and against the
+    implicit-GEMM form + unpack it replaces; written in the parameter layout; bitwise reproducible; refused for ragged geometries."""
+    import ctypes
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(7 * B + H + W)
+    x = torch.rand(B, 3, H, W, generator=g)
+    d = N.ConvDesc.make(B, H, W, 4, 64, 7, 2, 3)
+    dy = torch.randn(B, 64, d.Ho, d.Wo, generator=g)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 7, 7), dy.double(), 2, 3)
+    x4 = torch.zeros(B, H, W, 4, device=cuda)
+    x4[..., :3] = x.permute(0, 2, 3, 1).to(cuda)
+    dyg = T.nhwc(dy).to(cuda)
+    nb = L.osi_stem_wgrad_direct_workspace(ctypes.byref(d))
+    assert nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=cuda)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((64, 7, 7, 3), float("nan"), device=cuda)
+        N.check(L.osi_stem_wgrad_direct(ctypes.byref(d), N.ptr(dyg), N.ptr(x4), N.ptr(dw), N.ptr(ws), nb, T.S()))
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    got = T.oihw(outs[0]).cpu().double()
+    K = B * d.Ho * d.Wo
+    scale = float(dw64.abs().max())
+    assert float((got - dw64).abs().max()) <= (2e-6 + 6e-8 * K ** 0.5) * scale + 1e-6
+    gp = T.conv_wgrad(dyg, x4, 7, 2, 3)                                    # implicit-GEMM form, packed [64][224]
+    gk = torch.empty(64, 7, 7, 3, device=cuda)
+    N.check(L.osi_stem_grad_unpack(N.ptr(gp), N.ptr(gk), 64, T.S()))
+    assert float((gk - outs[0]).abs().max()) <= 2e-5 * scale
+    ragged = N.ConvDesc.make(B, 75, 91, 4, 64, 7, 2, 3)
+    assert L.osi_stem_wgrad_direct_workspace(ctypes.byref(ragged)) == 0
+    assert L.osi_stem_wgrad_direct(ctypes.byref(ragged), N.ptr(dyg), N.ptr(x4), N.ptr(outs[0]), N.ptr(ws), nb, T.S()) == -1
