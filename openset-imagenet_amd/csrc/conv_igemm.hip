@@ -86,6 +86,7 @@ __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, u
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x4acc __attribute__((ext_vector_type(4)));   // C/D of v_mfma_f32_16x16x4_f32
 __device__ __forceinline__ f32x3 bld3(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0));
 }
@@ -614,131 +615,229 @@ __global__ __launch_bounds__(256, 3) void k_stem_fwd_direct(const float* __restr
 }
 
 // ======================================================================================================
-// Stem weight gradient, direct form: dW[cout][k] = sum over pixels dY[pix][cout] * patch(pix)[k], k = (r * 7 + s) * 3 + c.
-// The implicit-GEMM kernel walks K = pixels with a 224-wide padded tap axis (147 real columns) and streams dY once per column tile
-// (4x). Here a workgroup of five waves owns the whole 64 x 160 gradient tile in registers (wave w = tap columns 32 w .. 32 w + 31,
-// both 32-cout row tiles), loops over its share of 8 x 16-pixel output tiles, and per tile stages the dY rows (32 KB, a straight
-// copy: the tile's rows are contiguous in NHWC) and the 21 x 37 x 3 input patch in LDS. K step = 2 pixels: A = dY[pix][cout] (conflict-
-// free), B = patch[base(pix) + tap offset of the lane's column] with the pixel base an immediate — as in k_stem_fwd_direct there is no
-// address arithmetic, no global load and no barrier inside the 64 K steps of a tile; the next tile's global loads are issued before
-// them and land in LDS after. Each workgroup writes ONE partial [64][147] slab; k_slab_reduce adds them in workgroup order (fixed,
-// bitwise reproducible) straight into the parameter-layout gradient [64][7][7][3] (no packed intermediate, no unpack pass).
+// Stem "outer product" kernel: C[c][k] = sum over pixels A[pix][c] * patch(pix)[k]  (c < 64 channels, k = (r * 7 + s) * 3 + ch < 147)
+// — the weight gradient of the 7x7 / stride-2 stem when A = dY, and the two moment matrices of the "backward by moments" below.
+// The implicit-GEMM weight-gradient kernel walks K = pixels with a 224-wide padded tap axis (147 real columns) and streams dY once
+// per column tile (4x). Here a workgroup of four waves owns the whole 64 x 160 tile in registers (wave w = channels 16 w .. 16 w + 15,
+// ten 16 x 16 accumulator tiles of v_mfma_f32_16x16x4_f32), loops over its share of 8 x 16-pixel output tiles, and per tile stages the
+// A rows (32 KB: the tile's rows are contiguous in NHWC) and the 21 x 37 x 3 input patch in LDS. K step = 4 pixels: A = one
+// ds_read_b32, B = ten gathers patch[pixel base + tap offset of the lane's column] with the pixel base an IMMEDIATE (the pixels of a K
+// step are neighbours in a tile row): no address arithmetic, no global load and no barrier inside the 32 K steps of a tile; the next
+// tile's global loads are issued before them (branch-free buffer loads into registers) and land in LDS behind them.
+// Each workgroup writes ONE partial [64][147] slab; k_slab_reduce adds them in workgroup order (fixed: bitwise reproducible).
+//   CENTER: the patch is centred, patch' = patch - mu[ch] (zero padding included: it becomes -mu). Exact for any A whose
+//           per-channel pixel sum is zero — the stem's dY after BatchNorm backward — and the conditioning of the moment form.
+//   PK:     also emits the per-tap sums of the (centred) patch over all pixels, Pk[k] (wave 0 adds its B operands up).
+//   SRC 0:  A is a tensor [B][Ho][Wo][64] (dY, or the stem's conv output for the moment matrix Yk).
+//   SRC 1:  A is the max-pool backward of the pooled gradient, rebuilt per tile from the pooled gradient + arg-max bytes staged in LDS
+//           (g[pix][c] = sum of the pooled gradients of the windows whose stored arg-max is pix and whose maximum was positive).
 // ======================================================================================================
-constexpr int SDW_THREADS = 320;
-__global__ __launch_bounds__(SDW_THREADS, 2) void k_stem_wgrad_direct(const float* __restrict__ dy, const float* __restrict__ x4,
-                                                                    float* __restrict__ slab, int B, int H, int W, int Ho, int Wo,
-                                                                    int tiles_x, int tiles_y, int ntiles, int tiles_per_wg) {
-    __shared__ __attribute__((aligned(16))) float sDY[128 * 64];
-    __shared__ float sP[SD_PH * SD_PW * 3 + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid / 64;
-    const int h = lane >> 5, l31 = lane & 31;
-    const int kcol = wave * 32 + l31;                      // this lane's tap column (>= 147: padding, never stored)
-    const float* pA = sDY + l31 + h * 64;
-    const float* pB = sP + sd_off(kcol) + h * 6;           // pixel 2 ks + 1 is the right-hand neighbour of pixel 2 ks: + 2 input pixels
-    constexpr int NDY = (128 * 16 + SDW_THREADS - 1) / SDW_THREADS;      // float4 per thread of a dY tile (7)
-    constexpr int NPX = (SD_PH * SD_PW + SDW_THREADS - 1) / SDW_THREADS; // patch pixels per thread (3)
-    f32x4 rdy[NDY];
+struct StemOuterP {
+    const float* a;            // SRC 0: [B][Ho][Wo][64]
+    const float* x4;           // [B][H][W][4]
+    float* slab;               // [groups][64][147]
+    float* pk_slab;            // PK: [groups][160]
+    const float* mu;           // CENTER: 3 (4) per-channel offsets
+    const float* pg;           // SRC 1: pooled gradient [B][Hp][Wp][64]
+    const uint32_t* pidx;      // SRC 1: arg-max bytes   [B][Hp][Wp][16] (bit 7 = ReLU gate, osi_bn_relu_maxpool_fwd)
+    int B, H, W, Ho, Wo, Hp, Wp, tiles_x, tiles_y, ntiles, tiles_per_wg;
+};
+constexpr int SO_QH = SD_TH / 2 + 1, SO_QW = SD_TW / 2 + 1;      // pooled windows that reach an 8 x 16 tile: 5 x 9
+template <int SRC, bool CENTER, bool PK>
+__global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
+    __shared__ __attribute__((aligned(16))) float sA[128 * 64];
+    __shared__ float sP[SD_PH * SD_PW * 3 + 3];
+    __shared__ __attribute__((aligned(16))) float sG[SRC == 1 ? SO_QH * SO_QW * 64 : 4];
+    __shared__ uint32_t sI[SRC == 1 ? SO_QH * SO_QW * 16 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo;
+    const float* pA = sA + lk * 64 + wave * 16 + l15;
+    const float* pB[10];
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) pB[nt] = sP + sd_off(nt * 16 + l15) + lk * 6;   // pixel 4 ks + lk: lk pixels to the right = 2 lk input pixels
+    constexpr int NPX = (SD_PH * SD_PW + 255) / 256;       // patch pixels per thread (4)
+    constexpr int NQ = (SO_QH * SO_QW * 16 + 255) / 256;   // SRC 1: pooled float4 / index words per thread (3)
+    f32x4 ra[SRC == 0 ? 8 : NQ];
+    uint32_t ri[SRC == 1 ? NQ : 1];
     f32x3 rpx[NPX];      // 12-byte loads: the 4th channel of the NHWC4 image is padding, and a dead 4th register would be reused by the
                          // allocator while the load is in flight (a vmcnt wait in front of the K loop)
-    // Branch-free loads (buffer descriptors, sentinel offset -> zeros): with conditional loads the compiler has to drain vmcnt at every
-    // control-flow merge, i.e. BEFORE the K loop, and the prefetch of the next tile is exposed instead of hidden behind 128 MFMAs.
-    const __amdgpu_buffer_rsrc_t rdyb = make_rsrc(dy, (int)((size_t)B * Ho * Wo * 64 * 4)), rxb = make_rsrc(x4, (int)((size_t)B * H * W * 16));
+    const __amdgpu_buffer_rsrc_t rab = make_rsrc(SRC == 0 ? p.a : p.pg, (int)((size_t)p.B * (SRC == 0 ? Ho * Wo : p.Hp * p.Wp) * 64 * 4));
+    const __amdgpu_buffer_rsrc_t rib = make_rsrc(SRC == 1 ? (const float*)p.pidx : p.x4, SRC == 1 ? (int)((size_t)p.B * p.Hp * p.Wp * 64) : 16);
+    const __amdgpu_buffer_rsrc_t rxb = make_rsrc(p.x4, (int)((size_t)p.B * H * W * 16));
     // per-thread offsets relative to the tile origin, computed once: the per-tile part is scalar
-    uint32_t drel[NDY], prel[NPX];
+    uint32_t prel[NPX];
     int ppy[NPX], ppx[NPX];
 #pragma unroll
-    for (int j = 0; j < NDY; ++j) {
-        const int f = tid + j * SDW_THREADS;               // float4 index inside the tile: row py = f / 256, then 16 pixels x 16 float4
-        drel[j] = f < 128 * 16 ? (uint32_t)((((f >> 8) * Wo) * 64 + (f & 255) * 4) * 4) : OOB;
-    }
-#pragma unroll
     for (int j = 0; j < NPX; ++j) {
-        const int i = tid + j * SDW_THREADS;
+        const int i = tid + j * 256;
         ppy[j] = i / SD_PW; ppx[j] = i - ppy[j] * SD_PW;
         prel[j] = (uint32_t)((ppy[j] * W + ppx[j]) * 16);
         if (i >= SD_PH * SD_PW) ppy[j] = 1 << 20;          // never inside the image
     }
+    int qy[NQ], qx[NQ];                                    // SRC 1: pooled pixel of this thread's float4 (relative to the tile's first window)
+    if (SRC == 1) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int i = tid + j * 256, q = i >> 4;
+            qy[j] = q / SO_QW; qx[j] = q - qy[j] * SO_QW;
+            if (i >= SO_QH * SO_QW * 16) qy[j] = 1 << 20;
+        }
+    }
+    f32x3 mu = {0.f, 0.f, 0.f};
+    if (CENTER) { mu[0] = p.mu[0]; mu[1] = p.mu[1]; mu[2] = p.mu[2]; }
     auto gload = [&](int tile) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
         const int oy0 = ty * SD_TH, ox0 = tx * SD_TW, iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
         // wave-uniform by construction (functions of the tile index); said explicitly, or hipcc wraps every load that takes the scalar
         // offset in a waterfall loop
-        const uint32_t dbase = (uint32_t)__builtin_amdgcn_readfirstlane(((b * Ho + oy0) * Wo + ox0) * 64 * 4);
-        const int pbase = __builtin_amdgcn_readfirstlane(((b * H + iy0) * W + ix0) * 16);   // may be negative at the image border: only used where the pixel is valid
+        const int pbase = __builtin_amdgcn_readfirstlane(((b * H + iy0) * W + ix0) * 16);   // may be negative at the border: only used where valid
         uint32_t poff[NPX];
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
             const int ok = ((unsigned)(iy0 + ppy[j]) < (unsigned)H) & ((unsigned)(ix0 + ppx[j]) < (unsigned)W);
             poff[j] = ok ? (uint32_t)(pbase + (int)prel[j]) : OOB;
         }
+        if (SRC == 0) {
+            const uint32_t abase = (uint32_t)__builtin_amdgcn_readfirstlane(((b * Ho + oy0) * Wo + ox0) * 64 * 4);
 #pragma unroll
-        for (int j = 0; j < NDY; ++j) rdy[j] = bld4(rdyb, drel[j], dbase);   // a sentinel offset stays out of range with the scalar base added
+            for (int j = 0; j < 8; ++j)      // row j of the tile: 16 pixels x 16 float4 = this thread's float4 tid of a 4 KB row
+                ra[j] = bld4(rab, (uint32_t)(tid * 16), abase + (uint32_t)(j * Wo * 256));
+        } else {
+            // windows ho = oy0 / 2 .. oy0 / 2 + 4, wo = ox0 / 2 .. ox0 / 2 + 8 (the last row / column may lie outside the pooled grid)
+            const int q0y = oy0 >> 1, q0x = ox0 >> 1;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int ok = ((unsigned)(q0y + qy[j]) < (unsigned)p.Hp) & ((unsigned)(q0x + qx[j]) < (unsigned)p.Wp);
+                const uint32_t qpix = (uint32_t)((b * p.Hp + q0y + qy[j]) * p.Wp + q0x + qx[j]);
+                ra[j] = bld4(rab, ok ? (qpix * 64 + (uint32_t)(tid & 15) * 4) * 4 : OOB, 0);
+                ri[j] = __builtin_amdgcn_raw_buffer_load_b32(rib, ok ? (qpix * 16 + (uint32_t)(tid & 15)) * 4 : OOB, 0, 0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NPX; ++j) rpx[j] = bld3(rxb, poff[j], 0);
     };
-    auto sstore = [&]() {
-#pragma unroll
-        for (int j = 0; j < NDY; ++j) {
-            const int f = tid + j * SDW_THREADS;
-            if (f < 128 * 16) *reinterpret_cast<f32x4*>(sDY + f * 4) = rdy[j];
-        }
+    auto sstore_patch = [&]() {
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
-            const int i = tid + j * SDW_THREADS;
-            if (i < SD_PH * SD_PW) { sP[i * 3] = rpx[j][0]; sP[i * 3 + 1] = rpx[j][1]; sP[i * 3 + 2] = rpx[j][2]; }
+            const int i = tid + j * 256;
+            if (i < SD_PH * SD_PW) { sP[i * 3] = rpx[j][0] - mu[0]; sP[i * 3 + 1] = rpx[j][1] - mu[1]; sP[i * 3 + 2] = rpx[j][2] - mu[2]; }
         }
     };
-    f32x16 acc[2];
+    auto sstore_a = [&](int tile) {
+        if (SRC == 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(sA + (j * 256 + tid) * 4) = ra[j];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    const int tile0 = blockIdx.x * tiles_per_wg, tile_end = min(ntiles, tile0 + tiles_per_wg);
-    if (tile0 < tile_end) {
-        gload(tile0);
-        sstore();
-        __syncthreads();
-        for (int tile = tile0; tile < tile_end; ++tile) {
-            if (tile + 1 < tile_end) gload(tile + 1);
-            // 64 K steps (2 pixels each) in groups of 4, LDS reads of group g + 1 issued before the MFMAs of group g (see k_stem_fwd_direct)
-            constexpr int G = 4, NG = 64 / G;
-            float ca0[G], ca1[G], cb[G];
-            auto lds_group = [&](int g, float (&a0)[G], float (&a1)[G], float (&bv)[G]) {
+            for (int j = 0; j < NQ; ++j) {
+                const int i = tid + j * 256;
+                if (i < SO_QH * SO_QW * 16) { *reinterpret_cast<f32x4*>(sG + i * 4) = ra[j]; sI[i] = ri[j]; }
+            }
+        }
+    };
+    // SRC 1: A tile from the staged pooled tile. Thread = (pixel column px = tid >> 4, channel quad c4 = tid & 15), rows py = 0..7.
+    // Pixel (h, w) belongs to windows ho in {h >> 1, (h + 1) >> 1}, wo likewise, at window position r = h - (2 ho - 1), s = w - (2 wo - 1);
+    // same visiting order as k_maxpool_bwd / pool_gather (bn.hip), so the sums are the ones the unfused route produces.
+    auto build_a = [&](int tile) {
+        const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
+        const int oy0 = ty * SD_TH, ox0 = tx * SD_TW, q0y = oy0 >> 1, q0x = ox0 >> 1;
+        const int px = tid >> 4, c4 = tid & 15, w = ox0 + px;
 #pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    const int ks = g * G + j, pix = 2 * ks;
-                    a0[j] = pA[ks * 128]; a1[j] = pA[ks * 128 + 32];
-                    bv[j] = pB[(2 * (pix >> 4) * SD_PW + 2 * (pix & 15)) * 3];
-                }
-            };
-            lds_group(0, ca0, ca1, cb);
+        for (int py = 0; py < 8; ++py) {
+            const int hh = oy0 + py;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                float na0[G], na1[G], nb[G];
-                if (g + 1 < NG) lds_group(g + 1, na0, na1, nb);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int dy = 0; dy < 2; ++dy) {
+                const int ho = dy == 0 ? hh >> 1 : (hh + 1) >> 1;
+                if (dy == 1 && ho == (hh >> 1)) continue;
+                if (ho >= p.Hp) continue;
+                const int r = hh - (2 * ho - 1);
 #pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[j], cb[j], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[j], cb[j], acc[1], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (g + 1 < NG) {
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int wo = dx == 0 ? w >> 1 : (w + 1) >> 1;
+                    if (dx == 1 && wo == (w >> 1)) continue;
+                    if (wo >= p.Wp) continue;
+                    const int sx = w - (2 * wo - 1);
+                    const int qi = ((ho - q0y) * SO_QW + (wo - q0x)) * 16 + c4;
+                    const uint32_t id = sI[qi];
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(sG + qi * 4);
+                    const uint32_t me = (uint32_t)(r * 3 + sx) | 0x80u;
 #pragma unroll
-                    for (int j = 0; j < G; ++j) { ca0[j] = na0[j]; ca1[j] = na1[j]; cb[j] = nb[j]; }
+                    for (int k = 0; k < 4; ++k)
+                        if (((id >> (8 * k)) & 0xffu) == me) acc[k] += g[k];
                 }
             }
+            *reinterpret_cast<f32x4*>(sA + ((py * 16 + px) * 16 + c4) * 4) = acc;
+        }
+    };
+    f32x4acc acc[10];
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) acc[nt] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+    float psum[10];
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) psum[nt] = 0.f;
+    const int tile0 = blockIdx.x * p.tiles_per_wg, tile_end = min(p.ntiles, tile0 + p.tiles_per_wg);
+    if (tile0 < tile_end) {
+        gload(tile0);
+        sstore_patch(); sstore_a(tile0);
+        __syncthreads();
+        if (SRC == 1) { build_a(tile0); __syncthreads(); }
+        for (int tile = tile0; tile < tile_end; ++tile) {
+            if (tile + 1 < tile_end) gload(tile + 1);
+            // 32 K steps (4 pixels each), the 11 LDS reads of step ks + 1 issued before the 10 MFMAs of step ks (two register sets)
+            struct Ops { float a, b[10]; };
+            auto lds_ops = [&](int ks, Ops& o) {
+                o.a = pA[ks * 256];
+                const int cb = (2 * (ks >> 2) * SD_PW + 8 * (ks & 3)) * 3;
+#pragma unroll
+                for (int nt = 0; nt < 10; ++nt) o.b[nt] = pB[nt][cb];
+            };
+            auto mma_ops = [&](const Ops& o) {
+#pragma unroll
+                for (int nt = 0; nt < 10; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a, o.b[nt], acc[nt], 0, 0, 0);
+                    if (PK) psum[nt] += o.b[nt];
+                }
+            };
+            Ops o0, o1;
+            lds_ops(0, o0);
+#pragma unroll
+            for (int ks = 0; ks < 32; ks += 2) {
+                lds_ops(ks + 1, o1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_ops(o0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < 32) lds_ops(ks + 2, o0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_ops(o1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             __syncthreads();                                // every wave is done reading this tile
-            if (tile + 1 < tile_end) { sstore(); __syncthreads(); }
+            if (tile + 1 < tile_end) {
+                sstore_patch(); sstore_a(tile + 1);
+                __syncthreads();
+                if (SRC == 1) { build_a(tile + 1); __syncthreads(); }
+            }
         }
     }
-    // partial gradient of this workgroup: rows = cout (accumulator rows), column = this lane's tap index
-    if (kcol < 147) {
-        float* out = slab + (size_t)blockIdx.x * (64 * 147);
+    // partial of this workgroup. C/D of 16x16x4: column (tap) = lane & 15, row (channel) = (lane >> 4) * 4 + reg
+    float* out = p.slab + (size_t)blockIdx.x * (64 * 147);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int nt = 0; nt < 10; ++nt) {
+        const int col = nt * 16 + l15;
+        if (col < 147) {
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) out[(i * 32 + acc_row(rr, lane)) * 147 + kcol] = acc[i][rr];
+            for (int e = 0; e < 4; ++e) out[(wave * 16 + lk * 4 + e) * 147 + col] = acc[nt][e];
+        }
+    }
+    if (PK && wave == 0) {      // every wave reads the same B operands: one of them adds them up (4 pixel groups of the lanes -> 1)
+#pragma unroll
+        for (int nt = 0; nt < 10; ++nt) {
+            float v = psum[nt];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane < 16) p.pk_slab[(size_t)blockIdx.x * 160 + nt * 16 + lane] = v;
+        }
     }
 }
 
@@ -1296,7 +1395,6 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 3 : (WM * WN == 2 ?
 // registers; the 18 MFMAs of a K step are independent (no accumulator latency exposed). dY traffic / 9, X traffic / (9 / window
 // amplification), LDS reads 12 per 18 MFMAs.
 // ======================================================================================================
-typedef float f32x4acc __attribute__((ext_vector_type(4)));
 constexpr int W3_BKP = 32;                 // pixels per K tile
 constexpr int W3_LDA = 64 + 16;            // dY image row stride (floats): 16 consecutive cout x 4 pixels per ds_read_b32 -> two pixel rows
 constexpr int W3_LDB = 32 + 16;            //   land on disjoint bank halves when the stride is 16 mod 32
@@ -2122,6 +2220,14 @@ static void stem_wgrad_plan(const osi_conv_desc* d, int& ntiles, int& per, int& 
     if (per < 1) per = 1;
     groups = osi_cdiv(ntiles, per);
 }
+static StemOuterP stem_outer_params(const osi_conv_desc* d, const float* a, const float* x4, float* slab, int ntiles, int per) {
+    StemOuterP q{};
+    q.a = a; q.x4 = x4; q.slab = slab;
+    q.B = d->B; q.H = d->H; q.W = d->W; q.Ho = d->Ho; q.Wo = d->Wo;
+    q.Hp = (d->Ho + 2 - 3) / 2 + 1; q.Wp = (d->Wo + 2 - 3) / 2 + 1;
+    q.tiles_x = d->Wo / SD_TW; q.tiles_y = d->Ho / SD_TH; q.ntiles = ntiles; q.tiles_per_wg = per;
+    return q;
+}
 size_t osi_stem_wgrad_direct_workspace(const osi_conv_desc* d) {
     if (!d || !stem_wgrad_direct_ok(d)) return 0;
     int ntiles, per, groups;
@@ -2136,8 +2242,8 @@ int osi_stem_wgrad_direct(const osi_conv_desc* d, const float* dy, const float* 
     stem_wgrad_plan(d, ntiles, per, groups);
     OSI_REQUIRE(ws_bytes >= (size_t)groups * 64 * 147 * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_stem_wgrad_direct, dim3(groups), dim3(SDW_THREADS), 0, st, dy, x4, (float*)ws, d->B, d->H, d->W, d->Ho, d->Wo,
-                       d->Wo / SD_TW, d->Ho / SD_TH, ntiles, per);
+    const StemOuterP q = stem_outer_params(d, dy, x4, (float*)ws, ntiles, per);
+    hipLaunchKernelGGL((k_stem_outer<0, false, false>), dim3(groups), dim3(256), 0, st, q);
     OSI_LAUNCH_CHECK();
     const size_t n4 = 64 * 147 / 4;
     hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)ws, dw_krsc3, n4, n4, groups);
