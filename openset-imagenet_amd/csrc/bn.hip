@@ -559,7 +559,7 @@ int osi_bn_apply_relu_mask2(const float* y, const float* scale, const float* shi
 static int bn_backward_impl(const float* dout, const void* msk, int mode, const float* y, const float* mean, const float* invstd,
                             const float* gamma, float* dy, float* gmasked, float* dgamma, float* dbeta, int M, int C, void* ws,
                             size_t ws_bytes, hipStream_t st, PoolSrc ps = PoolSrc{}) {
-    OSI_REQUIRE(dout && y && mean && invstd && gamma && dy && dgamma && dbeta && ws);
+    OSI_REQUIRE(dout && y && mean && invstd && gamma && (dy || mode == 3) && dgamma && dbeta && ws);
     OSI_REQUIRE(M > 0 && C > 0 && C % 4 == 0);
     int P;
     int rpb = rows_per_block(M, C, P);
@@ -576,6 +576,7 @@ static int bn_backward_impl(const float* dout, const void* msk, int mode, const 
     OSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, pdb, pdg, P, M, C, dgamma, dbeta, c1, c2);
     OSI_LAUNCH_CHECK();
+    if (!dy) return OSI_OK;     // reductions only (dgamma, dbeta): the caller assembles the consumer's gradient another way
     const size_t n4 = (size_t)M * C / 4;
     const int grid = stream_grid(n4), c4n = C / 4;
     auto D = (const f32x4*)dout; auto Y = (const f32x4*)y;

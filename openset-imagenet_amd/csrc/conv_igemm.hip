@@ -651,7 +651,8 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
     __shared__ uint32_t sI[SRC == 1 ? SO_QH * SO_QW * 16 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lk = lane >> 4;
-    const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo;
+    // scalars of the parameter block copied to locals: the lambdas below would otherwise pin the whole struct in scratch memory
+    const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo, Hp = p.Hp, Wp = p.Wp, tiles_x = p.tiles_x, tiles_y = p.tiles_y;
     const float* pA = sA + lk * 64 + wave * 16 + l15;
     const float* pB[10];
 #pragma unroll
@@ -662,8 +663,8 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
     uint32_t ri[SRC == 1 ? NQ : 1];
     f32x3 rpx[NPX];      // 12-byte loads: the 4th channel of the NHWC4 image is padding, and a dead 4th register would be reused by the
                          // allocator while the load is in flight (a vmcnt wait in front of the K loop)
-    const __amdgpu_buffer_rsrc_t rab = make_rsrc(SRC == 0 ? p.a : p.pg, (int)((size_t)p.B * (SRC == 0 ? Ho * Wo : p.Hp * p.Wp) * 64 * 4));
-    const __amdgpu_buffer_rsrc_t rib = make_rsrc(SRC == 1 ? (const float*)p.pidx : p.x4, SRC == 1 ? (int)((size_t)p.B * p.Hp * p.Wp * 64) : 16);
+    const __amdgpu_buffer_rsrc_t rab = make_rsrc(SRC == 0 ? p.a : p.pg, (int)((size_t)p.B * (SRC == 0 ? Ho * Wo : Hp * Wp) * 64 * 4));
+    const __amdgpu_buffer_rsrc_t rib = make_rsrc(SRC == 1 ? (const float*)p.pidx : p.x4, SRC == 1 ? (int)((size_t)p.B * Hp * Wp * 64) : 16);
     const __amdgpu_buffer_rsrc_t rxb = make_rsrc(p.x4, (int)((size_t)p.B * H * W * 16));
     // per-thread offsets relative to the tile origin, computed once: the per-tile part is scalar
     uint32_t prel[NPX];
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
     f32x3 mu = {0.f, 0.f, 0.f};
     if (CENTER) { mu[0] = p.mu[0]; mu[1] = p.mu[1]; mu[2] = p.mu[2]; }
     auto gload = [&](int tile) {
-        const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int oy0 = ty * SD_TH, ox0 = tx * SD_TW, iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
         // wave-uniform by construction (functions of the tile index); said explicitly, or hipcc wraps every load that takes the scalar
         // offset in a waterfall loop
@@ -708,8 +709,8 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
             const int q0y = oy0 >> 1, q0x = ox0 >> 1;
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                const int ok = ((unsigned)(q0y + qy[j]) < (unsigned)p.Hp) & ((unsigned)(q0x + qx[j]) < (unsigned)p.Wp);
-                const uint32_t qpix = (uint32_t)((b * p.Hp + q0y + qy[j]) * p.Wp + q0x + qx[j]);
+                const int ok = ((unsigned)(q0y + qy[j]) < (unsigned)Hp) & ((unsigned)(q0x + qx[j]) < (unsigned)Wp);
+                const uint32_t qpix = (uint32_t)((b * Hp + q0y + qy[j]) * Wp + q0x + qx[j]);
                 ra[j] = bld4(rab, ok ? (qpix * 64 + (uint32_t)(tid & 15) * 4) * 4 : OOB, 0);
                 ri[j] = __builtin_amdgcn_raw_buffer_load_b32(rib, ok ? (qpix * 16 + (uint32_t)(tid & 15)) * 4 : OOB, 0, 0);
             }
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
     // Pixel (h, w) belongs to windows ho in {h >> 1, (h + 1) >> 1}, wo likewise, at window position r = h - (2 ho - 1), s = w - (2 wo - 1);
     // same visiting order as k_maxpool_bwd / pool_gather (bn.hip), so the sums are the ones the unfused route produces.
     auto build_a = [&](int tile) {
-        const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
         const int oy0 = ty * SD_TH, ox0 = tx * SD_TW, q0y = oy0 >> 1, q0x = ox0 >> 1;
         const int px = tid >> 4, c4 = tid & 15, w = ox0 + px;
 #pragma unroll
@@ -751,13 +752,13 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
             for (int dy = 0; dy < 2; ++dy) {
                 const int ho = dy == 0 ? hh >> 1 : (hh + 1) >> 1;
                 if (dy == 1 && ho == (hh >> 1)) continue;
-                if (ho >= p.Hp) continue;
+                if (ho >= Hp) continue;
                 const int r = hh - (2 * ho - 1);
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     const int wo = dx == 0 ? w >> 1 : (w + 1) >> 1;
                     if (dx == 1 && wo == (w >> 1)) continue;
-                    if (wo >= p.Wp) continue;
+                    if (wo >= Wp) continue;
                     const int sx = w - (2 * wo - 1);
                     const int qi = ((ho - q0y) * SO_QW + (wo - q0x)) * 16 + c4;
                     const uint32_t id = sI[qi];
@@ -797,7 +798,12 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
 #pragma unroll
                 for (int nt = 0; nt < 10; ++nt) {
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a, o.b[nt], acc[nt], 0, 0, 0);
-                    if (PK) psum[nt] += o.b[nt];
+                }
+            };
+            auto pk_ops = [&](const Ops& o) {       // Pk: every wave reads the same B operands, wave 0 adds them up (wave-uniform branch)
+                if (PK && wave == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < 10; ++nt) psum[nt] += o.b[nt];
                 }
             };
             Ops o0, o1;
@@ -807,10 +813,12 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
                 lds_ops(ks + 1, o1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_ops(o0);
+                pk_ops(o0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks + 2 < 32) lds_ops(ks + 2, o0);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_ops(o1);
+                pk_ops(o1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                                // every wave is done reading this tile
@@ -1610,6 +1618,49 @@ __global__ __launch_bounds__(256) void k_conv_dgrad_tail_fixup(ConvP p) {
     });
 }
 
+// Per-channel mean of the NHWC4 image batch (the centring offsets of the stem's moment form): two fixed-order levels.
+__global__ __launch_bounds__(256) void k_x4_sum_partial(const f32x4* __restrict__ x4, size_t npix, f32x4* __restrict__ part) {
+    __shared__ f32x4 red[256];
+    f32x4 a = {0, 0, 0, 0}, b = a;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (; i + step < npix; i += 2 * step) { a += x4[i]; b += x4[i + step]; }
+    if (i < npix) a += x4[i];
+    red[threadIdx.x] = a + b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void k_x4_mean_final(const f32x4* __restrict__ part, int n, float inv_npix, f32x4* __restrict__ mu) {
+    __shared__ f32x4 red[256];
+    f32x4 a = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mu[0] = red[0] * inv_npix;
+}
+// Stem weight gradient from its moment matrices (see osi_stem_moments_backward):
+//   dW[c][k] = gamma_c invstd_c ( G[c][k] - c1_c Pk[k] - c2_c invstd_c (Yk[c][k] - mean_c Pk[k]) ),  c1 = dbeta / M, c2 = dgamma / M
+__global__ __launch_bounds__(256) void k_stem_moment_combine(const float* __restrict__ G, const float* __restrict__ Yk,
+                                                             const float* __restrict__ Pk, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                             float inv_m, float* __restrict__ dw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 64 * 147) return;
+    const int c = i / 147, k = i - c * 147;
+    const float is = invstd[c], c1 = dbeta[c] * inv_m, c2 = dgamma[c] * inv_m, pk = Pk[k];
+    const float xk = (Yk[i] - mean[c] * pk) * is;
+    dw[i] = (G[i] - c1 * pk - c2 * xk) * (gamma[c] * is);
+}
+
 // out[i] = sum_s slab[s][i]  (fixed order: bitwise reproducible)
 // One workgroup = 16 consecutive float4 outputs x 16 split lanes: lane j sums splits j, j+16, ... (4 independent loads in
 // flight), then the 16 lane partials are added in lane order. Many small dependent-latency chains instead of one long one.
@@ -2247,6 +2298,86 @@ int osi_stem_wgrad_direct(const osi_conv_desc* d, const float* dy, const float* 
     OSI_LAUNCH_CHECK();
     const size_t n4 = 64 * 147 / 4;
     hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)ws, dw_krsc3, n4, n4, groups);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+// ---- stem backward by moments ------------------------------------------------------------------------------------------------
+// The stem's weight gradient is dW = sum_pix dY (x) patch with dY = gamma invstd (g - c1 - xhat c2) (BatchNorm backward of the
+// max-pool-scattered gradient g). Expanding dY,
+//     dW[c][k] = gamma_c invstd_c ( G[c][k] - c1_c Pk[k] - c2_c invstd_c (Yk[c][k] - mean_c Pk[k]) )
+//     G = sum_pix g (x) patch'     Yk = sum_pix y (x) patch'     Pk = sum_pix patch'     patch' = patch - mu (centred: the dropped term
+//     mu * sum_pix dY vanishes because BatchNorm backward makes every channel of dY sum to zero; centring keeps the subtraction
+//     of the large common part c1 Pk out of the result's rounding error)
+// so the 112 x 112 x 64 gradient dY is never formed, Yk and Pk only need FORWARD data (computed beside the forward pass, off the
+// critical path), and at the end of the backward pass G (matrix-bound) runs BESIDE the BatchNorm reductions (HBM-bound) instead
+// of behind reductions + a 0.8 GB apply pass. Same products, another association: parity is checked against the fp64 oracle.
+size_t osi_stem_moments_workspace(const osi_conv_desc* d) {
+    if (!d || !stem_wgrad_direct_ok(d)) return 0;
+    int ntiles, per, groups;
+    stem_wgrad_plan(d, ntiles, per, groups);
+    return ((size_t)groups * (64 * 147 + 160) + 64 * 147 + 4 * 1024) * sizeof(float);
+}
+// forward part: moments[0 .. 9408) = Yk, [9408 .. 9568) = Pk, [9568 .. 9572) = mu (9 600 floats)
+int osi_stem_moments_forward(const osi_conv_desc* d, const float* y, const float* x4, float* moments, void* ws, size_t ws_bytes,
+                             osi_stream_t stream) {
+    OSI_REQUIRE(d && y && x4 && moments && ws);
+    if (!stem_wgrad_direct_ok(d)) return OSI_ERR_ARG;
+    OSI_REQUIRE(ws_bytes >= osi_stem_moments_workspace(d));
+    int ntiles, per, groups;
+    stem_wgrad_plan(d, ntiles, per, groups);
+    hipStream_t st = (hipStream_t)stream;
+    float* slab = (float*)ws;
+    float* pk_slab = slab + (size_t)groups * 64 * 147;
+    float* part = pk_slab + (size_t)groups * 160 + 64 * 147;
+    float* mu = moments + 64 * 147 + 160;
+    const size_t npix = (size_t)d->B * d->H * d->W;
+    hipLaunchKernelGGL(k_x4_sum_partial, dim3(1024), dim3(256), 0, st, (const f32x4*)x4, npix, (f32x4*)part);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_x4_mean_final, dim3(1), dim3(256), 0, st, (const f32x4*)part, 1024, 1.0f / (float)npix, (f32x4*)mu);
+    OSI_LAUNCH_CHECK();
+    StemOuterP q = stem_outer_params(d, y, x4, slab, ntiles, per);
+    q.pk_slab = pk_slab; q.mu = mu;
+    hipLaunchKernelGGL((k_stem_outer<0, true, true>), dim3(groups), dim3(256), 0, st, q);
+    OSI_LAUNCH_CHECK();
+    const size_t n4 = 64 * 147 / 4;
+    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)slab, moments, n4, n4, groups);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_slab_reduce, dim3(3), dim3(256), 0, st, (const float*)pk_slab, moments + 64 * 147, (size_t)40, (size_t)40, groups);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+// backward part 1 (needs only the pooled gradient): G into ws (first 9 408 floats behind the slabs)
+int osi_stem_moments_g(const osi_conv_desc* d, const float* gpool, const void* pool_idx, const float* x4, const float* moments, void* ws,
+                       size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(d && gpool && pool_idx && x4 && moments && ws);
+    if (!stem_wgrad_direct_ok(d)) return OSI_ERR_ARG;
+    OSI_REQUIRE(ws_bytes >= osi_stem_moments_workspace(d));
+    int ntiles, per, groups;
+    stem_wgrad_plan(d, ntiles, per, groups);
+    hipStream_t st = (hipStream_t)stream;
+    float* slab = (float*)ws;
+    float* G = slab + (size_t)groups * (64 * 147 + 160);
+    StemOuterP q = stem_outer_params(d, nullptr, x4, slab, ntiles, per);
+    q.pg = gpool; q.pidx = (const uint32_t*)pool_idx; q.mu = moments + 64 * 147 + 160;
+    hipLaunchKernelGGL((k_stem_outer<1, true, false>), dim3(groups), dim3(256), 0, st, q);
+    OSI_LAUNCH_CHECK();
+    const size_t n4 = 64 * 147 / 4;
+    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)slab, G, n4, n4, groups);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+// backward part 2 (needs dgamma / dbeta of the stem's BatchNorm): the parameter-layout gradient [64][7][7][3]
+int osi_stem_moments_combine(const osi_conv_desc* d, const float* moments, const void* ws, const float* gamma, const float* mean,
+                             const float* invstd, const float* dgamma, const float* dbeta, float* dw_krsc3, osi_stream_t stream) {
+    OSI_REQUIRE(d && moments && ws && gamma && mean && invstd && dgamma && dbeta && dw_krsc3);
+    if (!stem_wgrad_direct_ok(d)) return OSI_ERR_ARG;
+    int ntiles, per, groups;
+    stem_wgrad_plan(d, ntiles, per, groups);
+    const float* G = (const float*)ws + (size_t)groups * (64 * 147 + 160);
+    const float inv_m = 1.0f / (float)((size_t)d->B * d->Ho * d->Wo);
+    hipLaunchKernelGGL(k_stem_moment_combine, dim3(osi_cdiv(64 * 147, 256)), dim3(256), 0, (hipStream_t)stream, G, moments,
+                       moments + 64 * 147, gamma, mean, invstd, dgamma, dbeta, inv_m, dw_krsc3);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }

@@ -32,6 +32,36 @@ class _Node(nn.Module):
         raise RuntimeError("sub-modules of the MI355X ResNet50 are parameter containers; call the model itself")
 
 
+def debug_options_from_env():
+    """Development A/B switches of the executor, read from the environment in ONE place and handed over explicitly through
+    osi_resnet50_set_option (the library itself never reads the environment). Every default is the measured optimum; nothing here
+    is needed to run the product. {option name: value} for the variables that are set:
+        OSI_NO_OVERLAP=1      overlap 0           weight gradients stay on the main stream (serialised backward)
+        OSI_FWD_RECOMPUTE=1   fwd_recompute 1     conv1 recomputes the previous identity-shortcut block output in its loader
+        OSI_FWD_FORK=0        fwd_fork 0          projection shortcut of the forward pass on the main stream
+        OSI_STAGGER=1         stagger 1           weight gradients only beside BatchNorm-backward kernels, never beside an input gradient
+        OSI_SIDE_PRIO=n       side_priority_normal 1
+        OSI_STEM_MOMENTS=0    stem_moments 0      conv1's weight gradient from the materialised 112x112x64 gradient instead of by moments
+        OSI_FUSED_ACT=0       fused_act 0         in-block activations materialised by a BatchNorm-apply pass instead of in the loaders"""
+    env = os.environ
+    out = {}
+    if env.get("OSI_NO_OVERLAP"):
+        out["overlap"] = 0
+    if env.get("OSI_FWD_RECOMPUTE") == "1":
+        out["fwd_recompute"] = 1
+    if env.get("OSI_FWD_FORK") == "0":
+        out["fwd_fork"] = 0
+    if env.get("OSI_STAGGER") == "1":
+        out["stagger"] = 1
+    if env.get("OSI_SIDE_PRIO", "")[:1] == "n":
+        out["side_priority_normal"] = 1
+    if env.get("OSI_STEM_MOMENTS") == "0":
+        out["stem_moments"] = 0
+    if env.get("OSI_FUSED_ACT") == "0":
+        out["fused_act"] = 0
+    return out
+
+
 class _Net:
     """Owner of one executor handle (fixed batch / image size)."""
 
@@ -39,17 +69,8 @@ class _Net:
         self.h = ctypes.c_void_p()
         N.check(N.lib().osi_resnet50_create(ctypes.byref(self.h), B, H, W, F, O, int(bool(logit_bias))), "osi_resnet50_create")
         self.ws_bytes = N.lib().osi_resnet50_workspace_bytes(self.h)
-        # development A/B switches (environment read here, handed to the executor explicitly)
-        if os.environ.get("OSI_NO_OVERLAP"):     # keep the weight-gradient kernels on the main stream
-            N.check(N.lib().osi_resnet50_set_option(self.h, b"overlap", 0))
-        if os.environ.get("OSI_FWD_RECOMPUTE") == "1":
-            N.check(N.lib().osi_resnet50_set_option(self.h, b"fwd_recompute", 1))
-        if os.environ.get("OSI_FWD_FORK") == "0":
-            N.check(N.lib().osi_resnet50_set_option(self.h, b"fwd_fork", 0))
-        if os.environ.get("OSI_STAGGER") == "1":   # weight gradients beside the BatchNorm-backward kernels only, never beside an input gradient
-            N.check(N.lib().osi_resnet50_set_option(self.h, b"stagger", 1))
-        if os.environ.get("OSI_SIDE_PRIO", "")[:1] == "n":
-            N.check(N.lib().osi_resnet50_set_option(self.h, b"side_priority_normal", 1))
+        for name, value in debug_options_from_env().items():
+            N.check(N.lib().osi_resnet50_set_option(self.h, name.encode(), value), f"osi_resnet50_set_option({name})")
 
     def __del__(self):
         try:

@@ -145,3 +145,91 @@ def test_stem_direct_weight_gradient(cuda, B, H, W):
     ragged = N.ConvDesc.make(B, 75, 91, 4, 64, 7, 2, 3)
     assert L.osi_stem_wgrad_direct_workspace(ctypes.byref(ragged)) == 0
     assert L.osi_stem_wgrad_direct(ctypes.byref(ragged), N.ptr(dyg), N.ptr(x4), N.ptr(outs[0]), N.ptr(ws), nb, T.S()) == -1
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 96, 128), (4, 224, 224)])
+def test_stem_backward_by_moments(cuda, B, H, W):
+    """conv1's weight gradient assembled from the moment matrices (osi_stem_moments_forward / _g / _combine) against (a) the fp64
+    evaluation of the same mathematics on the SAME decisions (max-pool scatter through the stored arg-max bytes, BatchNorm backward,
+    conv2d_weight), and (b) the route it replaces (osi_bn_relu_maxpool_bwd + osi_stem_wgrad_direct on the materialised gradient).
+    The image is NOT centred around 0.5 (channel means 0.3 / 0.5 / 0.8) so that the centring by the measured channel means matters."""
+    import ctypes
+    import torch.nn.functional as F
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(31 * B + H)
+    x = (torch.rand(B, 3, H, W, generator=g) * 0.4 + torch.tensor([0.1, 0.3, 0.6]).view(1, 3, 1, 1))
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    d = N.ConvDesc.make(B, H, W, 4, 64, 7, 2, 3)
+    Ho, Wo = d.Ho, d.Wo
+    Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+    M = B * Ho * Wo
+    x4 = torch.zeros(B, H, W, 4, device=cuda)
+    x4[..., :3] = x.permute(0, 2, 3, 1).to(cuda)
+    y = T.nhwc(F.conv2d(x, w, None, 2, 3)).to(cuda).contiguous()                      # [B,Ho,Wo,64]
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(cuda), (torch.randn(64, generator=g) * 0.3).to(cuda)
+    yv = y.view(M, 64)
+    mean = yv.mean(0)
+    invstd = 1 / torch.sqrt(yv.var(0, unbiased=False) + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    pooled = torch.empty(B, Hp, Wp, 64, device=cuda)
+    idx = torch.zeros(B * Hp * Wp * 16, dtype=torch.int32, device=cuda)
+    N.check(L.osi_bn_relu_maxpool_fwd(N.ptr(y), N.ptr(scale), N.ptr(shift), N.ptr(pooled), N.ptr(idx), B, Ho, Wo, 64, T.S()))
+    gpool = torch.randn(B, Hp, Wp, 64, generator=g).to(cuda)
+    # ---- route it replaces: materialised dy, then the direct weight gradient
+    wsb = L.osi_bn_backward_workspace(M, 64)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    dy = torch.empty(B, Ho, Wo, 64, device=cuda)
+    dg0, db0 = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
+    N.check(L.osi_bn_relu_maxpool_bwd(N.ptr(gpool), N.ptr(idx), N.ptr(y), N.ptr(mean), N.ptr(invstd), N.ptr(gamma), N.ptr(dy), N.ptr(dg0), N.ptr(db0),
+                                      B, Ho, Wo, 64, N.ptr(ws), wsb, T.S()))
+    nbd = L.osi_stem_wgrad_direct_workspace(ctypes.byref(d))
+    wsd = torch.empty(nbd, dtype=torch.uint8, device=cuda)
+    dw_direct = torch.empty(64, 7, 7, 3, device=cuda)
+    N.check(L.osi_stem_wgrad_direct(ctypes.byref(d), N.ptr(dy), N.ptr(x4), N.ptr(dw_direct), N.ptr(wsd), nbd, T.S()))
+    # ---- by moments
+    nbm = L.osi_stem_moments_workspace(ctypes.byref(d))
+    assert nbm > 0
+    wsm = torch.empty(nbm, dtype=torch.uint8, device=cuda)
+    res = []
+    for _ in range(2):
+        mom = torch.full((9600,), float("nan"), device=cuda)
+        N.check(L.osi_stem_moments_forward(ctypes.byref(d), N.ptr(y), N.ptr(x4), N.ptr(mom), N.ptr(wsm), nbm, T.S()))
+        N.check(L.osi_stem_moments_g(ctypes.byref(d), N.ptr(gpool), N.ptr(idx), N.ptr(x4), N.ptr(mom), N.ptr(wsm), nbm, T.S()))
+        dg, db = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
+        N.check(L.osi_bn_relu_maxpool_bwd(N.ptr(gpool), N.ptr(idx), N.ptr(y), N.ptr(mean), N.ptr(invstd), N.ptr(gamma), None, N.ptr(dg), N.ptr(db),
+                                          B, Ho, Wo, 64, N.ptr(ws), wsb, T.S()))
+        dw = torch.full((64, 7, 7, 3), float("nan"), device=cuda)
+        N.check(L.osi_stem_moments_combine(ctypes.byref(d), N.ptr(mom), N.ptr(wsm), N.ptr(gamma), N.ptr(mean), N.ptr(invstd), N.ptr(dg), N.ptr(db),
+                                           N.ptr(dw), T.S()))
+        res.append((dw, mom, dg, db))
+    dw, mom, dg, db = res[0]
+    assert torch.equal(dw, res[1][0]) and torch.equal(mom[:9572], res[1][1][:9572]), "bitwise reproducible"
+    assert torch.equal(dg, dg0) and torch.equal(db, db0), "the reductions-only call produces the same dgamma / dbeta"
+    # channel means of the image (4th slot: the zero padding channel)
+    assert torch.allclose(mom[9568:9571].cpu(), x.mean(dim=(0, 2, 3)), atol=1e-5) and float(mom[9571]) == 0
+    # ---- fp64 evaluation of the same mathematics on the same decisions
+    ib = idx.view(B, Hp, Wp, 16).cpu().numpy().view("uint8").reshape(B, Hp, Wp, 64)        # one byte per channel
+    ib = torch.from_numpy(ib.astype("int64"))
+    gp = gpool.cpu().double()
+    g64 = torch.zeros(B, Ho, Wo, 64, dtype=torch.float64)
+    gate = (ib >= 128)
+    tap = ib % 128
+    for r in range(3):
+        for s_ in range(3):
+            sel = gate & (tap == r * 3 + s_)
+            hh = (torch.arange(Hp) * 2 - 1 + r).clamp(0, Ho - 1)
+            ww = (torch.arange(Wp) * 2 - 1 + s_).clamp(0, Wo - 1)
+            contrib = torch.where(sel, gp, torch.zeros_like(gp))
+            g64.index_put_((torch.arange(B).view(B, 1, 1), hh.view(1, Hp, 1), ww.view(1, 1, Wp)), contrib, accumulate=True)
+    y64, mu64, is64 = y.cpu().double(), mean.cpu().double(), invstd.cpu().double()
+    xh = (y64 - mu64) * is64
+    c1, c2 = g64.view(M, 64).mean(0), (g64 * xh).view(M, 64).mean(0)
+    dy64 = (g64 - c1 - xh * c2) * (gamma.cpu().double() * is64)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 7, 7), dy64.permute(0, 3, 1, 2), 2, 3)
+    got, old = T.oihw(dw).cpu().double(), T.oihw(dw_direct).cpu().double()
+    rel = lambda a: float((a - dw64).norm() / dw64.norm())
+    print(f"B{B} {H}x{W}: rel-L2 vs fp64: by moments {rel(got):.2e}, materialised route {rel(old):.2e}")
+    assert rel(old) <= 5e-5 and rel(got) <= 5e-5
+    assert float((got - dw64).abs().max()) <= 2e-4 * float(dw64.abs().max())
