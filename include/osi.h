@@ -113,23 +113,16 @@ int osi_stem_weight_pack(const float* w_krsc3, float* w_packed, int Cout, osi_st
  * osi_stem_wgrad_direct_workspace returns 0 for a geometry it does not take (use osi_conv_wgrad + osi_stem_grad_unpack then);
  * osi_stem_wgrad_direct returns OSI_ERR_ARG for it. x4 = the NHWC4 image the forward read. */
 size_t osi_stem_wgrad_direct_workspace(const osi_conv_desc* d);
-/* Stem backward "by moments" (same geometries as osi_stem_wgrad_direct). The weight gradient of conv1 behind bn1 -> ReLU ->
- * max-pool (torchvision ResNet._forward_impl under model.py:17, differentiated at train.py:138) is assembled from three moment
- * matrices instead of the 112 x 112 x 64 gradient tensor:
- *   osi_stem_moments_forward  (any time after the stem convolution of the SAME step; forward data only): channel means of the
- *                             image, Yk = sum y (x) patch', Pk = sum patch' -> moments (9 600 floats: Yk [64][147] | Pk [160] | mu [4])
- *   osi_stem_moments_g        (as soon as the pooled gradient exists): G = sum maxpool_bwd(gpool) (x) patch' -> ws
- *   osi_stem_moments_combine  (after the BatchNorm reductions, e.g. osi_bn_relu_maxpool_bwd with dy = NULL): dw [64][7][7][3]
- * ws: osi_stem_moments_workspace(d) bytes, the same buffer for _g and _combine (0 = geometry not taken). Deterministic. */
-size_t osi_stem_moments_workspace(const osi_conv_desc* d);
-int osi_stem_moments_forward(const osi_conv_desc* d, const float* y, const float* x4, float* moments, void* ws, size_t ws_bytes,
-                             osi_stream_t stream);
-int osi_stem_moments_g(const osi_conv_desc* d, const float* gpool, const void* pool_idx, const float* x4, const float* moments, void* ws,
-                       size_t ws_bytes, osi_stream_t stream);
-int osi_stem_moments_combine(const osi_conv_desc* d, const float* moments, const void* ws, const float* gamma, const float* mean,
-                             const float* invstd, const float* dgamma, const float* dbeta, float* dw_krsc3, osi_stream_t stream);
 int osi_stem_wgrad_direct(const osi_conv_desc* d, const float* dy, const float* x4, float* dw_krsc3, void* ws, size_t ws_bytes,
                           osi_stream_t stream);
+/* The same gradient with the whole stem tail fused into the operand loader: dY = BatchNorm backward of the ReLU-gated max-pool
+ * scatter of gpool (the gradient w.r.t. the pooled activation) is built per tile in LDS from gpool, the arg-max bytes of
+ * osi_bn_relu_maxpool_fwd and the stem's conv output y, and never written to memory. dgamma / dbeta: the stem BatchNorm's reductions
+ * (osi_bn_relu_maxpool_bwd with dy = NULL computes exactly those). ws: osi_stem_wgrad_fused_workspace(d) bytes. */
+size_t osi_stem_wgrad_fused_workspace(const osi_conv_desc* d);
+int osi_stem_wgrad_fused(const osi_conv_desc* d, const float* gpool, const void* pool_idx, const float* y, const float* x4,
+                         const float* gamma, const float* mean, const float* invstd, const float* dgamma, const float* dbeta,
+                         float* dw_krsc3, void* ws, size_t ws_bytes, osi_stream_t stream);
 int osi_stem_grad_unpack(const float* g_packed, float* g_krsc3, int Cout, osi_stream_t stream);
 
 /* ---- BatchNorm2d in training mode + ReLU + residual (torchvision Bottleneck under model.py:37; train() at train.py:125) --- */

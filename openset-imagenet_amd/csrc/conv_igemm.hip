@@ -615,8 +615,7 @@ __global__ __launch_bounds__(256, 3) void k_stem_fwd_direct(const float* __restr
 }
 
 // ======================================================================================================
-// Stem "outer product" kernel: C[c][k] = sum over pixels A[pix][c] * patch(pix)[k]  (c < 64 channels, k = (r * 7 + s) * 3 + ch < 147)
-// — the weight gradient of the 7x7 / stride-2 stem when A = dY, and the two moment matrices of the "backward by moments" below.
+// Stem weight gradient, direct form: dW[c][k] = sum over pixels dY[pix][c] * patch(pix)[k]  (c < 64 channels, k = (r * 7 + s) * 3 + ch < 147).
 // The implicit-GEMM weight-gradient kernel walks K = pixels with a 224-wide padded tap axis (147 real columns) and streams dY once
 // per column tile (4x). Here a workgroup of four waves owns the whole 64 x 160 tile in registers (wave w = channels 16 w .. 16 w + 15,
 // ten 16 x 16 accumulator tiles of v_mfma_f32_16x16x4_f32), loops over its share of 8 x 16-pixel output tiles, and per tile stages the
@@ -625,30 +624,37 @@ __global__ __launch_bounds__(256, 3) void k_stem_fwd_direct(const float* __restr
 // step are neighbours in a tile row): no address arithmetic, no global load and no barrier inside the 32 K steps of a tile; the next
 // tile's global loads are issued before them (branch-free buffer loads into registers) and land in LDS behind them.
 // Each workgroup writes ONE partial [64][147] slab; k_slab_reduce adds them in workgroup order (fixed: bitwise reproducible).
-//   CENTER: the patch is centred, patch' = patch - mu[ch] (zero padding included: it becomes -mu). Exact for any A whose
-//           per-channel pixel sum is zero — the stem's dY after BatchNorm backward — and the conditioning of the moment form.
-//   PK:     also emits the per-tap sums of the (centred) patch over all pixels, Pk[k] (wave 0 adds its B operands up).
-//   SRC 0:  A is a tensor [B][Ho][Wo][64] (dY, or the stem's conv output for the moment matrix Yk).
-//   SRC 1:  A is the max-pool backward of the pooled gradient, rebuilt per tile from the pooled gradient + arg-max bytes staged in LDS
-//           (g[pix][c] = sum of the pooled gradients of the windows whose stored arg-max is pix and whose maximum was positive).
+//   SRC 0:  dY is a tensor [B][Ho][Wo][64] in memory.
+//   SRC 2:  dY is never written to memory: it is the BatchNorm backward (g - c1 - xhat c2) gamma invstd of the max-pool backward g of
+//           the pooled gradient (g[pix][c] = sum of the pooled gradients of the windows whose stored arg-max is pix and whose maximum
+//           was positive), built per tile from the pooled gradient + arg-max bytes staged in LDS and the prefetched rows of the
+//           stem's conv output y — the stem tail bn1 -> ReLU -> max-pool differentiated inside the operand loader.
+// (A third form — conv1's gradient assembled from the moment matrices sum g (x) patch, sum y (x) patch, sum patch, so that the matrix
+// work runs beside the BatchNorm reductions — was built, exact (5e-7 .. 2e-6 of fp64) and NOT faster: the forward-time moment GEMM
+// cost the forward pass what the backward gained, 34.87 vs 34.96 ms. Removed; profiles/NOTES_r03.md.)
 // ======================================================================================================
 struct StemOuterP {
-    const float* a;            // SRC 0: [B][Ho][Wo][64]
+    const float* a;            // SRC 0: dY, SRC 2: the stem's conv output y; [B][Ho][Wo][64]
     const float* x4;           // [B][H][W][4]
     float* slab;               // [groups][64][147]
-    float* pk_slab;            // PK: [groups][160]
-    const float* mu;           // CENTER: 3 (4) per-channel offsets
-    const float* pg;           // SRC 1: pooled gradient [B][Hp][Wp][64]
-    const uint32_t* pidx;      // SRC 1: arg-max bytes   [B][Hp][Wp][16] (bit 7 = ReLU gate, osi_bn_relu_maxpool_fwd)
+    const float* pg;           // SRC 2: pooled gradient [B][Hp][Wp][64]
+    const uint32_t* pidx;      // SRC 2: arg-max bytes   [B][Hp][Wp][16] (bit 7 = ReLU gate, osi_bn_relu_maxpool_fwd)
+    const float *gamma, *mean, *invstd, *dgamma, *dbeta;   // SRC 2: the stem BatchNorm's parameters, statistics and reductions
+    float inv_m;               // SRC 2: 1 / (B * Ho * Wo)
     int B, H, W, Ho, Wo, Hp, Wp, tiles_x, tiles_y, ntiles, tiles_per_wg;
 };
 constexpr int SO_QH = SD_TH / 2 + 1, SO_QW = SD_TW / 2 + 1;      // pooled windows that reach an 8 x 16 tile: 5 x 9
-template <int SRC, bool CENTER, bool PK>
-__global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
+template <int SRC>
+// SRC 2 holds 32 more prefetch registers (the rows of y): two waves per SIMD without spills measure the same as three with (396 vs 400 us)
+__global__ __launch_bounds__(256, SRC == 2 ? 2 : 3) void k_stem_outer(StemOuterP p) {
     __shared__ __attribute__((aligned(16))) float sA[128 * 64];
-    __shared__ float sP[SD_PH * SD_PW * 3 + 3];
-    __shared__ __attribute__((aligned(16))) float sG[SRC == 1 ? SO_QH * SO_QW * 64 : 4];
-    __shared__ uint32_t sI[SRC == 1 ? SO_QH * SO_QW * 16 : 1];
+    // The patch (read by the K loop) and the staged pooled tile (read only while the A tile is being built) share their memory:
+    // 46 KB per workgroup instead of 56, i.e. three resident workgroups per CU instead of two; the patch is stored after build_a.
+    constexpr int SO_PFLOATS = SD_PH * SD_PW * 3 + 3, SO_GFLOATS = SO_QH * SO_QW * (64 + 16);
+    __shared__ __attribute__((aligned(16))) float sU[SRC != 0 ? (SO_PFLOATS > SO_GFLOATS ? SO_PFLOATS : SO_GFLOATS) : SO_PFLOATS];
+    float* const sP = sU;
+    float* const sG = sU;
+    uint32_t* const sI = reinterpret_cast<uint32_t*>(sU + SO_QH * SO_QW * 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lk = lane >> 4;
     // scalars of the parameter block copied to locals: the lambdas below would otherwise pin the whole struct in scratch memory
@@ -659,12 +665,14 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
     for (int nt = 0; nt < 10; ++nt) pB[nt] = sP + sd_off(nt * 16 + l15) + lk * 6;   // pixel 4 ks + lk: lk pixels to the right = 2 lk input pixels
     constexpr int NPX = (SD_PH * SD_PW + 255) / 256;       // patch pixels per thread (4)
     constexpr int NQ = (SO_QH * SO_QW * 16 + 255) / 256;   // SRC 1: pooled float4 / index words per thread (3)
-    f32x4 ra[SRC == 0 ? 8 : NQ];
-    uint32_t ri[SRC == 1 ? NQ : 1];
+    f32x4 ra[8];                     // the tile's rows of dY (SRC 0) / of the stem's conv output y (SRC 2)
+    f32x4 rq[SRC != 0 ? NQ : 1];     // SRC 2: pooled gradient float4
+    uint32_t ri[SRC != 0 ? NQ : 1];  //        and arg-max words of the windows that reach the tile
     f32x3 rpx[NPX];      // 12-byte loads: the 4th channel of the NHWC4 image is padding, and a dead 4th register would be reused by the
                          // allocator while the load is in flight (a vmcnt wait in front of the K loop)
-    const __amdgpu_buffer_rsrc_t rab = make_rsrc(SRC == 0 ? p.a : p.pg, (int)((size_t)p.B * (SRC == 0 ? Ho * Wo : Hp * Wp) * 64 * 4));
-    const __amdgpu_buffer_rsrc_t rib = make_rsrc(SRC == 1 ? (const float*)p.pidx : p.x4, SRC == 1 ? (int)((size_t)p.B * Hp * Wp * 64) : 16);
+    const __amdgpu_buffer_rsrc_t rab = make_rsrc(p.a, (int)((size_t)p.B * Ho * Wo * 64 * 4));
+    const __amdgpu_buffer_rsrc_t rqb = make_rsrc(SRC != 0 ? p.pg : p.x4, SRC != 0 ? (int)((size_t)p.B * Hp * Wp * 64 * 4) : 16);
+    const __amdgpu_buffer_rsrc_t rib = make_rsrc(SRC != 0 ? (const float*)p.pidx : p.x4, SRC != 0 ? (int)((size_t)p.B * Hp * Wp * 64) : 16);
     const __amdgpu_buffer_rsrc_t rxb = make_rsrc(p.x4, (int)((size_t)p.B * H * W * 16));
     // per-thread offsets relative to the tile origin, computed once: the per-tile part is scalar
     uint32_t prel[NPX];
@@ -676,8 +684,8 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
         prel[j] = (uint32_t)((ppy[j] * W + ppx[j]) * 16);
         if (i >= SD_PH * SD_PW) ppy[j] = 1 << 20;          // never inside the image
     }
-    int qy[NQ], qx[NQ];                                    // SRC 1: pooled pixel of this thread's float4 (relative to the tile's first window)
-    if (SRC == 1) {
+    int qy[NQ], qx[NQ];                                    // SRC 2: pooled pixel of this thread's float4 (relative to the tile's first window)
+    if (SRC != 0) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int i = tid + j * 256, q = i >> 4;
@@ -685,8 +693,14 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
             if (i >= SO_QH * SO_QW * 16) qy[j] = 1 << 20;
         }
     }
-    f32x3 mu = {0.f, 0.f, 0.f};
-    if (CENTER) { mu[0] = p.mu[0]; mu[1] = p.mu[1]; mu[2] = p.mu[2]; }
+    // SRC 2: BatchNorm-backward coefficients of this thread's four channels (c4 = tid & 15):
+    //   A = (g - c1 - xhat c2) gamma invstd,  xhat = (y - mean) invstd,  c1 = dbeta / M,  c2 = dgamma / M
+    f32x4 bc1 = {0, 0, 0, 0}, bc2 = bc1, bmu = bc1, bis = bc1, bgs = bc1;
+    if (SRC == 2) {
+        const int c = (tid & 15) * 4;
+        bc1 = ld4(p.dbeta + c) * p.inv_m; bc2 = ld4(p.dgamma + c) * p.inv_m;
+        bmu = ld4(p.mean + c); bis = ld4(p.invstd + c); bgs = ld4(p.gamma + c) * bis;
+    }
     auto gload = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int oy0 = ty * SD_TH, ox0 = tx * SD_TW, iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
@@ -699,19 +713,20 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
             const int ok = ((unsigned)(iy0 + ppy[j]) < (unsigned)H) & ((unsigned)(ix0 + ppx[j]) < (unsigned)W);
             poff[j] = ok ? (uint32_t)(pbase + (int)prel[j]) : OOB;
         }
-        if (SRC == 0) {
+        {
             const uint32_t abase = (uint32_t)__builtin_amdgcn_readfirstlane(((b * Ho + oy0) * Wo + ox0) * 64 * 4);
 #pragma unroll
             for (int j = 0; j < 8; ++j)      // row j of the tile: 16 pixels x 16 float4 = this thread's float4 tid of a 4 KB row
                 ra[j] = bld4(rab, (uint32_t)(tid * 16), abase + (uint32_t)(j * Wo * 256));
-        } else {
+        }
+        if (SRC != 0) {
             // windows ho = oy0 / 2 .. oy0 / 2 + 4, wo = ox0 / 2 .. ox0 / 2 + 8 (the last row / column may lie outside the pooled grid)
             const int q0y = oy0 >> 1, q0x = ox0 >> 1;
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const int ok = ((unsigned)(q0y + qy[j]) < (unsigned)Hp) & ((unsigned)(q0x + qx[j]) < (unsigned)Wp);
                 const uint32_t qpix = (uint32_t)((b * Hp + q0y + qy[j]) * Wp + q0x + qx[j]);
-                ra[j] = bld4(rab, ok ? (qpix * 64 + (uint32_t)(tid & 15) * 4) * 4 : OOB, 0);
+                rq[j] = bld4(rqb, ok ? (qpix * 64 + (uint32_t)(tid & 15) * 4) * 4 : OOB, 0);
                 ri[j] = __builtin_amdgcn_raw_buffer_load_b32(rib, ok ? (qpix * 16 + (uint32_t)(tid & 15)) * 4 : OOB, 0, 0);
             }
         }
@@ -722,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
             const int i = tid + j * 256;
-            if (i < SD_PH * SD_PW) { sP[i * 3] = rpx[j][0] - mu[0]; sP[i * 3 + 1] = rpx[j][1] - mu[1]; sP[i * 3 + 2] = rpx[j][2] - mu[2]; }
+            if (i < SD_PH * SD_PW) { sP[i * 3] = rpx[j][0]; sP[i * 3 + 1] = rpx[j][1]; sP[i * 3 + 2] = rpx[j][2]; }
         }
     };
     auto sstore_a = [&](int tile) {
@@ -733,11 +748,11 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const int i = tid + j * 256;
-                if (i < SO_QH * SO_QW * 16) { *reinterpret_cast<f32x4*>(sG + i * 4) = ra[j]; sI[i] = ri[j]; }
+                if (i < SO_QH * SO_QW * 16) { *reinterpret_cast<f32x4*>(sG + i * 4) = rq[j]; sI[i] = ri[j]; }
             }
         }
     };
-    // SRC 1: A tile from the staged pooled tile. Thread = (pixel column px = tid >> 4, channel quad c4 = tid & 15), rows py = 0..7.
+    // SRC 2: A tile from the staged pooled tile. Thread = (pixel column px = tid >> 4, channel quad c4 = tid & 15), rows py = 0..7.
     // Pixel (h, w) belongs to windows ho in {h >> 1, (h + 1) >> 1}, wo likewise, at window position r = h - (2 ho - 1), s = w - (2 wo - 1);
     // same visiting order as k_maxpool_bwd / pool_gather (bn.hip), so the sums are the ones the unfused route produces.
     auto build_a = [&](int tile) {
@@ -769,21 +784,21 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
                         if (((id >> (8 * k)) & 0xffu) == me) acc[k] += g[k];
                 }
             }
+            if (SRC == 2) {     // BatchNorm backward of the scattered gradient, with the y row this thread prefetched
+                const f32x4 xh = (ra[py] - bmu) * bis;
+                acc = (acc - bc1 - xh * bc2) * bgs;
+            }
             *reinterpret_cast<f32x4*>(sA + ((py * 16 + px) * 16 + c4) * 4) = acc;
         }
     };
     f32x4acc acc[10];
 #pragma unroll
     for (int nt = 0; nt < 10; ++nt) acc[nt] = f32x4acc{0.f, 0.f, 0.f, 0.f};
-    float psum[10];
-#pragma unroll
-    for (int nt = 0; nt < 10; ++nt) psum[nt] = 0.f;
     const int tile0 = blockIdx.x * p.tiles_per_wg, tile_end = min(p.ntiles, tile0 + p.tiles_per_wg);
     if (tile0 < tile_end) {
         gload(tile0);
-        sstore_patch(); sstore_a(tile0);
-        __syncthreads();
-        if (SRC == 1) { build_a(tile0); __syncthreads(); }
+        if (SRC == 0) { sstore_patch(); sstore_a(tile0); __syncthreads(); }
+        else { sstore_a(tile0); __syncthreads(); build_a(tile0); __syncthreads(); sstore_patch(); __syncthreads(); }
         for (int tile = tile0; tile < tile_end; ++tile) {
             if (tile + 1 < tile_end) gload(tile + 1);
             // 32 K steps (4 pixels each), the 11 LDS reads of step ks + 1 issued before the 10 MFMAs of step ks (two register sets)
@@ -800,12 +815,6 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a, o.b[nt], acc[nt], 0, 0, 0);
                 }
             };
-            auto pk_ops = [&](const Ops& o) {       // Pk: every wave reads the same B operands, wave 0 adds them up (wave-uniform branch)
-                if (PK && wave == 0) {
-#pragma unroll
-                    for (int nt = 0; nt < 10; ++nt) psum[nt] += o.b[nt];
-                }
-            };
             Ops o0, o1;
             lds_ops(0, o0);
 #pragma unroll
@@ -813,19 +822,16 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
                 lds_ops(ks + 1, o1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_ops(o0);
-                pk_ops(o0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks + 2 < 32) lds_ops(ks + 2, o0);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_ops(o1);
-                pk_ops(o1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                                // every wave is done reading this tile
             if (tile + 1 < tile_end) {
-                sstore_patch(); sstore_a(tile + 1);
-                __syncthreads();
-                if (SRC == 1) { build_a(tile + 1); __syncthreads(); }
+                if (SRC == 0) { sstore_patch(); sstore_a(tile + 1); __syncthreads(); }
+                else { sstore_a(tile + 1); __syncthreads(); build_a(tile + 1); __syncthreads(); sstore_patch(); __syncthreads(); }
             }
         }
     }
@@ -837,14 +843,6 @@ __global__ __launch_bounds__(256, 2) void k_stem_outer(StemOuterP p) {
         if (col < 147) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) out[(wave * 16 + lk * 4 + e) * 147 + col] = acc[nt][e];
-        }
-    }
-    if (PK && wave == 0) {      // every wave reads the same B operands: one of them adds them up (4 pixel groups of the lanes -> 1)
-#pragma unroll
-        for (int nt = 0; nt < 10; ++nt) {
-            float v = psum[nt];
-            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-            if (lane < 16) p.pk_slab[(size_t)blockIdx.x * 160 + nt * 16 + lane] = v;
         }
     }
 }
@@ -1618,49 +1616,6 @@ __global__ __launch_bounds__(256) void k_conv_dgrad_tail_fixup(ConvP p) {
     });
 }
 
-// Per-channel mean of the NHWC4 image batch (the centring offsets of the stem's moment form): two fixed-order levels.
-__global__ __launch_bounds__(256) void k_x4_sum_partial(const f32x4* __restrict__ x4, size_t npix, f32x4* __restrict__ part) {
-    __shared__ f32x4 red[256];
-    f32x4 a = {0, 0, 0, 0}, b = a;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t step = (size_t)gridDim.x * 256;
-    for (; i + step < npix; i += 2 * step) { a += x4[i]; b += x4[i + step]; }
-    if (i < npix) a += x4[i];
-    red[threadIdx.x] = a + b;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
-}
-__global__ __launch_bounds__(256) void k_x4_mean_final(const f32x4* __restrict__ part, int n, float inv_npix, f32x4* __restrict__ mu) {
-    __shared__ f32x4 red[256];
-    f32x4 a = {0, 0, 0, 0};
-    for (int i = threadIdx.x; i < n; i += 256) a += part[i];
-    red[threadIdx.x] = a;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) mu[0] = red[0] * inv_npix;
-}
-// Stem weight gradient from its moment matrices (see osi_stem_moments_backward):
-//   dW[c][k] = gamma_c invstd_c ( G[c][k] - c1_c Pk[k] - c2_c invstd_c (Yk[c][k] - mean_c Pk[k]) ),  c1 = dbeta / M, c2 = dgamma / M
-__global__ __launch_bounds__(256) void k_stem_moment_combine(const float* __restrict__ G, const float* __restrict__ Yk,
-                                                             const float* __restrict__ Pk, const float* __restrict__ gamma,
-                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                             float inv_m, float* __restrict__ dw) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 64 * 147) return;
-    const int c = i / 147, k = i - c * 147;
-    const float is = invstd[c], c1 = dbeta[c] * inv_m, c2 = dgamma[c] * inv_m, pk = Pk[k];
-    const float xk = (Yk[i] - mean[c] * pk) * is;
-    dw[i] = (G[i] - c1 * pk - c2 * xk) * (gamma[c] * is);
-}
-
 // out[i] = sum_s slab[s][i]  (fixed order: bitwise reproducible)
 // One workgroup = 16 consecutive float4 outputs x 16 split lanes: lane j sums splits j, j+16, ... (4 independent loads in
 // flight), then the 16 lane partials are added in lane order. Many small dependent-latency chains instead of one long one.
@@ -2294,7 +2249,7 @@ int osi_stem_wgrad_direct(const osi_conv_desc* d, const float* dy, const float* 
     OSI_REQUIRE(ws_bytes >= (size_t)groups * 64 * 147 * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     const StemOuterP q = stem_outer_params(d, dy, x4, (float*)ws, ntiles, per);
-    hipLaunchKernelGGL((k_stem_outer<0, false, false>), dim3(groups), dim3(256), 0, st, q);
+    hipLaunchKernelGGL((k_stem_outer<0>), dim3(groups), dim3(256), 0, st, q);
     OSI_LAUNCH_CHECK();
     const size_t n4 = 64 * 147 / 4;
     hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)ws, dw_krsc3, n4, n4, groups);
@@ -2302,82 +2257,27 @@ int osi_stem_wgrad_direct(const osi_conv_desc* d, const float* dy, const float* 
     return OSI_OK;
 }
 
-// ---- stem backward by moments ------------------------------------------------------------------------------------------------
-// The stem's weight gradient is dW = sum_pix dY (x) patch with dY = gamma invstd (g - c1 - xhat c2) (BatchNorm backward of the
-// max-pool-scattered gradient g). Expanding dY,
-//     dW[c][k] = gamma_c invstd_c ( G[c][k] - c1_c Pk[k] - c2_c invstd_c (Yk[c][k] - mean_c Pk[k]) )
-//     G = sum_pix g (x) patch'     Yk = sum_pix y (x) patch'     Pk = sum_pix patch'     patch' = patch - mu (centred: the dropped term
-//     mu * sum_pix dY vanishes because BatchNorm backward makes every channel of dY sum to zero; centring keeps the subtraction
-//     of the large common part c1 Pk out of the result's rounding error)
-// so the 112 x 112 x 64 gradient dY is never formed, Yk and Pk only need FORWARD data (computed beside the forward pass, off the
-// critical path), and at the end of the backward pass G (matrix-bound) runs BESIDE the BatchNorm reductions (HBM-bound) instead
-// of behind reductions + a 0.8 GB apply pass. Same products, another association: parity is checked against the fp64 oracle.
-size_t osi_stem_moments_workspace(const osi_conv_desc* d) {
-    if (!d || !stem_wgrad_direct_ok(d)) return 0;
-    int ntiles, per, groups;
-    stem_wgrad_plan(d, ntiles, per, groups);
-    return ((size_t)groups * (64 * 147 + 160) + 64 * 147 + 4 * 1024) * sizeof(float);
-}
-// forward part: moments[0 .. 9408) = Yk, [9408 .. 9568) = Pk, [9568 .. 9572) = mu (9 600 floats)
-int osi_stem_moments_forward(const osi_conv_desc* d, const float* y, const float* x4, float* moments, void* ws, size_t ws_bytes,
-                             osi_stream_t stream) {
-    OSI_REQUIRE(d && y && x4 && moments && ws);
+// Stem weight gradient with the BatchNorm + ReLU + max-pool backward fused into its operand loader (k_stem_outer<2>): the
+// 112 x 112 x 64 gradient dY is built per tile in LDS from the pooled gradient, the arg-max bytes and the stem's conv output and is
+// never written to memory — no apply pass (0.8 GB of traffic) between the BatchNorm reductions and the weight gradient.
+size_t osi_stem_wgrad_fused_workspace(const osi_conv_desc* d) { return osi_stem_wgrad_direct_workspace(d); }
+int osi_stem_wgrad_fused(const osi_conv_desc* d, const float* gpool, const void* pool_idx, const float* y, const float* x4,
+                         const float* gamma, const float* mean, const float* invstd, const float* dgamma, const float* dbeta,
+                         float* dw_krsc3, void* ws, size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(d && gpool && pool_idx && y && x4 && gamma && mean && invstd && dgamma && dbeta && dw_krsc3 && ws);
     if (!stem_wgrad_direct_ok(d)) return OSI_ERR_ARG;
-    OSI_REQUIRE(ws_bytes >= osi_stem_moments_workspace(d));
     int ntiles, per, groups;
     stem_wgrad_plan(d, ntiles, per, groups);
+    OSI_REQUIRE(ws_bytes >= (size_t)groups * 64 * 147 * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
-    float* slab = (float*)ws;
-    float* pk_slab = slab + (size_t)groups * 64 * 147;
-    float* part = pk_slab + (size_t)groups * 160 + 64 * 147;
-    float* mu = moments + 64 * 147 + 160;
-    const size_t npix = (size_t)d->B * d->H * d->W;
-    hipLaunchKernelGGL(k_x4_sum_partial, dim3(1024), dim3(256), 0, st, (const f32x4*)x4, npix, (f32x4*)part);
-    OSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_x4_mean_final, dim3(1), dim3(256), 0, st, (const f32x4*)part, 1024, 1.0f / (float)npix, (f32x4*)mu);
-    OSI_LAUNCH_CHECK();
-    StemOuterP q = stem_outer_params(d, y, x4, slab, ntiles, per);
-    q.pk_slab = pk_slab; q.mu = mu;
-    hipLaunchKernelGGL((k_stem_outer<0, true, true>), dim3(groups), dim3(256), 0, st, q);
+    StemOuterP q = stem_outer_params(d, y, x4, (float*)ws, ntiles, per);
+    q.pg = gpool; q.pidx = (const uint32_t*)pool_idx;
+    q.gamma = gamma; q.mean = mean; q.invstd = invstd; q.dgamma = dgamma; q.dbeta = dbeta;
+    q.inv_m = 1.0f / (float)((size_t)d->B * d->Ho * d->Wo);
+    hipLaunchKernelGGL((k_stem_outer<2>), dim3(groups), dim3(256), 0, st, q);
     OSI_LAUNCH_CHECK();
     const size_t n4 = 64 * 147 / 4;
-    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)slab, moments, n4, n4, groups);
-    OSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_slab_reduce, dim3(3), dim3(256), 0, st, (const float*)pk_slab, moments + 64 * 147, (size_t)40, (size_t)40, groups);
-    OSI_LAUNCH_CHECK();
-    return OSI_OK;
-}
-// backward part 1 (needs only the pooled gradient): G into ws (first 9 408 floats behind the slabs)
-int osi_stem_moments_g(const osi_conv_desc* d, const float* gpool, const void* pool_idx, const float* x4, const float* moments, void* ws,
-                       size_t ws_bytes, osi_stream_t stream) {
-    OSI_REQUIRE(d && gpool && pool_idx && x4 && moments && ws);
-    if (!stem_wgrad_direct_ok(d)) return OSI_ERR_ARG;
-    OSI_REQUIRE(ws_bytes >= osi_stem_moments_workspace(d));
-    int ntiles, per, groups;
-    stem_wgrad_plan(d, ntiles, per, groups);
-    hipStream_t st = (hipStream_t)stream;
-    float* slab = (float*)ws;
-    float* G = slab + (size_t)groups * (64 * 147 + 160);
-    StemOuterP q = stem_outer_params(d, nullptr, x4, slab, ntiles, per);
-    q.pg = gpool; q.pidx = (const uint32_t*)pool_idx; q.mu = moments + 64 * 147 + 160;
-    hipLaunchKernelGGL((k_stem_outer<1, true, false>), dim3(groups), dim3(256), 0, st, q);
-    OSI_LAUNCH_CHECK();
-    const size_t n4 = 64 * 147 / 4;
-    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)slab, G, n4, n4, groups);
-    OSI_LAUNCH_CHECK();
-    return OSI_OK;
-}
-// backward part 2 (needs dgamma / dbeta of the stem's BatchNorm): the parameter-layout gradient [64][7][7][3]
-int osi_stem_moments_combine(const osi_conv_desc* d, const float* moments, const void* ws, const float* gamma, const float* mean,
-                             const float* invstd, const float* dgamma, const float* dbeta, float* dw_krsc3, osi_stream_t stream) {
-    OSI_REQUIRE(d && moments && ws && gamma && mean && invstd && dgamma && dbeta && dw_krsc3);
-    if (!stem_wgrad_direct_ok(d)) return OSI_ERR_ARG;
-    int ntiles, per, groups;
-    stem_wgrad_plan(d, ntiles, per, groups);
-    const float* G = (const float*)ws + (size_t)groups * (64 * 147 + 160);
-    const float inv_m = 1.0f / (float)((size_t)d->B * d->Ho * d->Wo);
-    hipLaunchKernelGGL(k_stem_moment_combine, dim3(osi_cdiv(64 * 147, 256)), dim3(256), 0, (hipStream_t)stream, G, moments,
-                       moments + 64 * 147, gamma, mean, invstd, dgamma, dbeta, inv_m, dw_krsc3);
+    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)ws, dw_krsc3, n4, n4, groups);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }

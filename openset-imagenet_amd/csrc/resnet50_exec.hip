@@ -65,7 +65,6 @@ struct osi_resnet50 {
     // stem
     int Hs, Ws, Hp, Wp;              // stem conv output, maxpool output
     size_t x4, wpack, gpack, a_pool, pool_idx, pooled, feat, logits_ws;
-    size_t stem_mom;                 // stem backward by moments: Yk | Pk | mu (osi_stem_moments_forward), 9 600 floats
     size_t bn_ws, bn_ws2, bn_ws_bytes, wg_ws, wg_ws_bytes, dg_ws, dg_ws_bytes;   // bn_ws2: BatchNorm scratch of the side-stream branch
     static constexpr int NSCR = 12;   // scratch activations-gradient buffers (each = largest activation)
     size_t scratch[NSCR], scratch_floats;
@@ -97,7 +96,7 @@ struct osi_resnet50 {
             prof_ev.push_back(e); prof_cls.push_back(0); prof_side.push_back(0);
         }
         prof_cls[prof_n] = cls;
-        prof_side[prof_n] = (side != nullptr && st == side) ? 1 : ((side2 != nullptr && st == side2) ? 2 : 0);
+        prof_side[prof_n] = (side != nullptr && st == side) ? 1 : 0;
         if (hipEventRecord(prof_ev[prof_n], st) != hipSuccess) return OSI_ERR_LAUNCH;
         ++prof_n;
         return OSI_OK;
@@ -152,13 +151,8 @@ struct osi_resnet50 {
     bool side_prio_normal = false;   // side stream at default instead of lowest priority (read when the stream is created)
     const float* x4_ext = nullptr;   // external NHWC4 input bound by osi_resnet50_bind_input_nhwc4 (consumed by one forward)
     const float* x4_cur = nullptr;   // input of the step in flight (forward sets it, the stem weight gradient reads it)
-    // Stem backward by moments (osi_stem_moments_*): the forward computes the moment matrices of the stem's output beside the main
-    // branch on a third stream, the backward assembles conv1's weight gradient from them and never forms the 112 x 112 x 64 gradient
-    bool stem_moments = true;        // option "stem_moments" (taken where the geometry allows: osi_stem_moments_workspace > 0)
-    bool mom_pending = false;        // this step's forward part is in flight on side2 (ev_mom_done)
-    bool mom_valid = false;          // the moments buffer belongs to the latest training forward
-    hipStream_t side2 = nullptr;
-    hipEvent_t ev_mom_fork = nullptr, ev_mom_done = nullptr, ev_bnst = nullptr;
+    bool stem_fused = true;          // option "stem_fused": conv1's weight gradient builds dY in its operand loader (osi_stem_wgrad_fused)
+                                     // behind the BatchNorm reductions: no 112x112x64 gradient tensor, no apply pass (step -0.15 ms)
     bool stagger = false;            // option "stagger": a weight gradient starts when the input gradient of the SAME layer has finished
                                      // (beside the next BatchNorm-backward kernels) and the next input gradient waits for it: matrix-bound
                                      // kernels never co-run, only HBM-bound work overlaps them. A/B against the default co-running schedule.
@@ -180,10 +174,6 @@ struct osi_resnet50 {
         if (hipEventCreateWithFlags(&ev_wdone, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
         for (int i = 0; i < NSCR; ++i)
             if (hipEventCreateWithFlags(&buf_ev[i], hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
-        if (hipStreamCreateWithPriority(&side2, hipStreamNonBlocking, lo) != hipSuccess) return OSI_ERR_LAUNCH;
-        if (hipEventCreateWithFlags(&ev_mom_fork, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
-        if (hipEventCreateWithFlags(&ev_mom_done, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
-        if (hipEventCreateWithFlags(&ev_bnst, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
         return OSI_OK;
     }
     bool async_wgrad() const { return overlap && (!prof_on || prof_timeline) && side != nullptr; }
@@ -215,11 +205,6 @@ struct osi_resnet50 {
             (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_wdone);
             for (int i = 0; i < NSCR; ++i) (void)hipEventDestroy(buf_ev[i]);
             (void)hipStreamDestroy(side);
-            if (side2) {
-                (void)hipStreamSynchronize(side2);
-                (void)hipEventDestroy(ev_mom_fork); (void)hipEventDestroy(ev_mom_done); (void)hipEventDestroy(ev_bnst);
-                (void)hipStreamDestroy(side2);
-            }
         }
     }
 };
@@ -235,7 +220,6 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
     n->x4 = n->ws_alloc((size_t)B * H * W * 4);
     n->wpack = n->ws_alloc(64 * 224);
     n->gpack = n->ws_alloc(64 * 224);
-    n->stem_mom = n->ws_alloc(9600);
     int stem = n->add_conv_bn(rb + "conv1", rb + "bn1", B, H, W, 4, 64, 7, 2, 3, false);   // its activation only exists max-pooled
     n->Hs = n->convs[stem].d.Ho; n->Ws = n->convs[stem].d.Wo;
     n->Hp = (n->Hs + 2 - 3) / 2 + 1; n->Wp = (n->Ws + 2 - 3) / 2 + 1;
@@ -294,8 +278,6 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
         size_t wg = osi_conv_wgrad_workspace(&c.d);
         if (wg > wgws) wgws = wg;
         wg = osi_stem_wgrad_direct_workspace(&c.d);
-        if (wg > wgws) wgws = wg;
-        wg = osi_stem_moments_workspace(&c.d);
         if (wg > wgws) wgws = wg;
         if (!(c.d.Cin == 4 && c.d.R == 7)) { size_t dg = osi_conv_dgrad_fused_workspace(&c.d); if (dg > dgws) dgws = dg; }
     }
@@ -460,25 +442,6 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     OSI_TRY(osi_stem_weight_pack(params + c0.w_off, ws + n->wpack, 64, st));
     OSI_TRY(n->mark(OSI_PROF_OTHER, st));
     OSI_TRY(conv_bn_fwd(n, 0, params, buffers, ws, x4, ws + n->wpack, training, st, n->bn_ws));
-    n->mom_valid = false;
-    if (training && n->stem_moments && osi_stem_moments_workspace(&c0.d) > 0) {
-        // moment matrices of the stem output (forward data only), beside the rest of the forward pass: nothing reads them before
-        // the very end of the backward pass
-        const bool async = n->async_wgrad();
-        hipStream_t ms = st;
-        if (async) {
-            if (hipEventRecord(n->ev_mom_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
-            if (hipStreamWaitEvent(n->side2, n->ev_mom_fork, 0) != hipSuccess) return OSI_ERR_LAUNCH;
-            ms = n->side2;
-        }
-        OSI_TRY(osi_stem_moments_forward(&c0.d, ws + c0.y, x4, ws + n->stem_mom, ws + n->wg_ws, n->wg_ws_bytes, ms));
-        if (async) {
-            if (hipEventRecord(n->ev_mom_done, n->side2) != hipSuccess) return OSI_ERR_LAUNCH;
-            n->mom_pending = true;
-        }
-        OSI_TRY(n->mark(OSI_PROF_CONV_WGRAD, ms));
-        n->mom_valid = true;
-    }
     BN& b0 = n->bns[c0.bn];
     // bn1 + relu + maxpool in one pass: the 112x112x64 post-ReLU tensor is never materialised
     OSI_TRY(osi_bn_relu_maxpool_fwd(ws + c0.y, ws + b0.scale, ws + b0.shift, ws + n->a_pool, ws + n->pool_idx, n->B, n->Hs, n->Ws, 64, st));
@@ -782,11 +745,6 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
     for (int stage = stage_lo; stage < stage_hi; ++stage) {
         if (stage == 0) {
             OSI_REQUIRE(dlogits);
-            if (n->mom_pending) {   // the forward's moment kernels used the weight-gradient workspace and wrote the moments buffer
-                if (hipStreamWaitEvent(st, n->ev_mom_done, 0) != hipSuccess) return OSI_ERR_LAUNCH;
-                if (n->side && hipStreamWaitEvent(n->side, n->ev_mom_done, 0) != hipSuccess) return OSI_ERR_LAUNCH;
-                n->mom_pending = false;
-            }
             n->free_list.clear();
             for (int i = 0; i < osi_resnet50::NSCR; ++i) { n->free_list.push_back(i); n->buf_pending[i] = false; }
             const Tensor& fw = n->tensors[n->t_fc_w]; const Tensor& fb = n->tensors[n->t_fc_b]; const Tensor& lw = n->tensors[n->t_lg_w];
@@ -821,10 +779,13 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             if (t < 0) return t;
             BN& b0 = n->bns[c0.bn];
             const float* x4c = n->x4_cur ? n->x4_cur : ws + n->x4;
-            if (n->stem_moments && n->mom_valid && osi_stem_moments_workspace(&c0.d) > 0) {
-                // by moments: G (matrix-bound, needs only the pooled gradient) on the side stream BESIDE the BatchNorm reductions
-                // (HBM-bound) on the main stream, then a 9 408-element combine; no 112x112x64 gradient, no apply pass
+            if (n->stem_fused && osi_stem_wgrad_fused_workspace(&c0.d) > 0) {
+                // reductions of bn1's backward (dgamma, dbeta) on the main stream, then the weight gradient with the max-pool scatter,
+                // ReLU gate and BatchNorm backward applied inside its operand loader: the 112x112x64 gradient is never written
                 n->give(t);
+                OSI_TRY(osi_bn_relu_maxpool_bwd(S(go), ws + n->pool_idx, ws + c0.y, ws + b0.mean, ws + b0.invstd, params + b0.g_off, nullptr,
+                                                grads + b0.g_off, grads + b0.b_off, n->B, n->Hs, n->Ws, 64, ws + n->bn_ws, n->bn_ws_bytes, st));
+                OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
                 const bool async = n->async_wgrad();
                 hipStream_t gs = st;
                 if (async) {
@@ -832,23 +793,14 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
                     if (hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) return OSI_ERR_LAUNCH;
                     gs = n->side;
                 }
-                OSI_TRY(osi_stem_moments_g(&c0.d, S(go), ws + n->pool_idx, x4c, ws + n->stem_mom, ws + n->wg_ws, n->wg_ws_bytes, gs));
-                OSI_TRY(n->mark(OSI_PROF_CONV_WGRAD, gs));
-                OSI_TRY(osi_bn_relu_maxpool_bwd(S(go), ws + n->pool_idx, ws + c0.y, ws + b0.mean, ws + b0.invstd, params + b0.g_off, nullptr,
-                                                grads + b0.g_off, grads + b0.b_off, n->B, n->Hs, n->Ws, 64, ws + n->bn_ws, n->bn_ws_bytes, st));
-                OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
-                if (async) {
-                    if (hipEventRecord(n->ev_bnst, st) != hipSuccess) return OSI_ERR_LAUNCH;
-                    if (hipStreamWaitEvent(n->side, n->ev_bnst, 0) != hipSuccess) return OSI_ERR_LAUNCH;
-                }
-                OSI_TRY(osi_stem_moments_combine(&c0.d, ws + n->stem_mom, ws + n->wg_ws, params + b0.g_off, ws + b0.mean, ws + b0.invstd,
-                                                 grads + b0.g_off, grads + b0.b_off, grads + c0.w_off, gs));
+                OSI_TRY(osi_stem_wgrad_fused(&c0.d, S(go), ws + n->pool_idx, ws + c0.y, x4c, params + b0.g_off, ws + b0.mean, ws + b0.invstd,
+                                             grads + b0.g_off, grads + b0.b_off, grads + c0.w_off, ws + n->wg_ws, n->wg_ws_bytes, gs));
                 if (async) {
                     if (hipEventRecord(n->buf_ev[go], n->side) != hipSuccess) return OSI_ERR_LAUNCH;
                     n->buf_pending[go] = true;
                     n->side_dirty = true;
                 }
-                OSI_TRY(n->mark(OSI_PROF_OTHER, gs));
+                OSI_TRY(n->mark(OSI_PROF_CONV_WGRAD, gs));
                 n->give(go);
             } else {
                 // max-pool scatter + ReLU gate + bn1 backward gathered on the fly from the pooled gradient (no 112x112x64 gradient)
@@ -971,7 +923,7 @@ int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
     else if (!strcmp(name, "fwd_fork")) n->fwd_fork = value != 0;
     else if (!strcmp(name, "stagger")) n->stagger = value != 0;
     else if (!strcmp(name, "fwd_recompute")) n->fwd_recompute = value != 0;
-    else if (!strcmp(name, "stem_moments")) n->stem_moments = value != 0;
+    else if (!strcmp(name, "stem_fused")) n->stem_fused = value != 0;
     else if (!strcmp(name, "side_priority_normal")) {
         if (n->side) return OSI_ERR_STATE;   // the side stream already exists with the other priority
         n->side_prio_normal = value != 0;

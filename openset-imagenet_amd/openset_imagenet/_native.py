@@ -54,10 +54,8 @@ _SIGS = {
     "osi_stem_weight_pack": (c_int, [P, P, c_int, P]),
     "osi_stem_wgrad_direct_workspace": (c_size_t, [_PD]),
     "osi_stem_wgrad_direct": (c_int, [_PD, P, P, P, P, c_size_t, P]),
-    "osi_stem_moments_workspace": (c_size_t, [_PD]),
-    "osi_stem_moments_forward": (c_int, [_PD, P, P, P, P, c_size_t, P]),
-    "osi_stem_moments_g": (c_int, [_PD, P, P, P, P, P, c_size_t, P]),
-    "osi_stem_moments_combine": (c_int, [_PD, P, P, P, P, P, P, P, P, P]),
+    "osi_stem_wgrad_fused_workspace": (c_size_t, [_PD]),
+    "osi_stem_wgrad_fused": (c_int, [_PD, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "osi_stem_grad_unpack": (c_int, [P, P, c_int, P]),
     "osi_bn_workspace": (c_size_t, [c_int, c_int]),
     "osi_bn_train_stats": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),

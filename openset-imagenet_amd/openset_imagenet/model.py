@@ -41,7 +41,7 @@ def debug_options_from_env():
         OSI_FWD_FORK=0        fwd_fork 0          projection shortcut of the forward pass on the main stream
         OSI_STAGGER=1         stagger 1           weight gradients only beside BatchNorm-backward kernels, never beside an input gradient
         OSI_SIDE_PRIO=n       side_priority_normal 1
-        OSI_STEM_MOMENTS=0    stem_moments 0      conv1's weight gradient from the materialised 112x112x64 gradient instead of by moments
+        OSI_STEM_FUSED=0      stem_fused 0        conv1's weight gradient from a materialised 112x112x64 gradient (BatchNorm apply pass)
         OSI_FUSED_ACT=0       fused_act 0         in-block activations materialised by a BatchNorm-apply pass instead of in the loaders"""
     env = os.environ
     out = {}
@@ -55,8 +55,8 @@ def debug_options_from_env():
         out["stagger"] = 1
     if env.get("OSI_SIDE_PRIO", "")[:1] == "n":
         out["side_priority_normal"] = 1
-    if env.get("OSI_STEM_MOMENTS") == "0":
-        out["stem_moments"] = 0
+    if env.get("OSI_STEM_FUSED") == "0":
+        out["stem_fused"] = 0
     if env.get("OSI_FUSED_ACT") == "0":
         out["fused_act"] = 0
     return out

@@ -148,11 +148,11 @@ def test_stem_direct_weight_gradient(cuda, B, H, W):
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 96, 128), (4, 224, 224)])
-def test_stem_backward_by_moments(cuda, B, H, W):
-    """conv1's weight gradient assembled from the moment matrices (osi_stem_moments_forward / _g / _combine) against (a) the fp64
-    evaluation of the same mathematics on the SAME decisions (max-pool scatter through the stored arg-max bytes, BatchNorm backward,
-    conv2d_weight), and (b) the route it replaces (osi_bn_relu_maxpool_bwd + osi_stem_wgrad_direct on the materialised gradient).
-    The image is NOT centred around 0.5 (channel means 0.3 / 0.5 / 0.8) so that the centring by the measured channel means matters."""
+def test_stem_weight_gradient_with_fused_tail(cuda, B, H, W):
+    """conv1's weight gradient with the stem tail (bn1 -> ReLU -> max-pool) differentiated inside its operand loader
+    (osi_stem_wgrad_fused) against (a) the fp64 evaluation of the same mathematics on the SAME decisions (max-pool scatter through
+    the stored arg-max bytes, BatchNorm backward, conv2d_weight), and (b) the route it replaces (osi_bn_relu_maxpool_bwd writing the
+    112x112x64 gradient + osi_stem_wgrad_direct reading it back)."""
     import ctypes
     import torch.nn.functional as F
     import osi_testlib as T
@@ -188,27 +188,21 @@ def test_stem_backward_by_moments(cuda, B, H, W):
     wsd = torch.empty(nbd, dtype=torch.uint8, device=cuda)
     dw_direct = torch.empty(64, 7, 7, 3, device=cuda)
     N.check(L.osi_stem_wgrad_direct(ctypes.byref(d), N.ptr(dy), N.ptr(x4), N.ptr(dw_direct), N.ptr(wsd), nbd, T.S()))
-    # ---- by moments
-    nbm = L.osi_stem_moments_workspace(ctypes.byref(d))
-    assert nbm > 0
-    wsm = torch.empty(nbm, dtype=torch.uint8, device=cuda)
-    res = []
+    # ---- fused: dY built in the weight gradient's operand loader from gpool, the arg-max bytes and y
+    nbf = L.osi_stem_wgrad_fused_workspace(ctypes.byref(d))
+    wsf = torch.empty(nbf, dtype=torch.uint8, device=cuda)
+    fused = []
     for _ in range(2):
-        mom = torch.full((9600,), float("nan"), device=cuda)
-        N.check(L.osi_stem_moments_forward(ctypes.byref(d), N.ptr(y), N.ptr(x4), N.ptr(mom), N.ptr(wsm), nbm, T.S()))
-        N.check(L.osi_stem_moments_g(ctypes.byref(d), N.ptr(gpool), N.ptr(idx), N.ptr(x4), N.ptr(mom), N.ptr(wsm), nbm, T.S()))
-        dg, db = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
-        N.check(L.osi_bn_relu_maxpool_bwd(N.ptr(gpool), N.ptr(idx), N.ptr(y), N.ptr(mean), N.ptr(invstd), N.ptr(gamma), None, N.ptr(dg), N.ptr(db),
-                                          B, Ho, Wo, 64, N.ptr(ws), wsb, T.S()))
-        dw = torch.full((64, 7, 7, 3), float("nan"), device=cuda)
-        N.check(L.osi_stem_moments_combine(ctypes.byref(d), N.ptr(mom), N.ptr(wsm), N.ptr(gamma), N.ptr(mean), N.ptr(invstd), N.ptr(dg), N.ptr(db),
-                                           N.ptr(dw), T.S()))
-        res.append((dw, mom, dg, db))
-    dw, mom, dg, db = res[0]
-    assert torch.equal(dw, res[1][0]) and torch.equal(mom[:9572], res[1][1][:9572]), "bitwise reproducible"
-    assert torch.equal(dg, dg0) and torch.equal(db, db0), "the reductions-only call produces the same dgamma / dbeta"
-    # channel means of the image (4th slot: the zero padding channel)
-    assert torch.allclose(mom[9568:9571].cpu(), x.mean(dim=(0, 2, 3)), atol=1e-5) and float(mom[9571]) == 0
+        dwf = torch.full((64, 7, 7, 3), float("nan"), device=cuda)
+        N.check(L.osi_stem_wgrad_fused(ctypes.byref(d), N.ptr(gpool), N.ptr(idx), N.ptr(y), N.ptr(x4), N.ptr(gamma), N.ptr(mean), N.ptr(invstd),
+                                       N.ptr(dg0), N.ptr(db0), N.ptr(dwf), N.ptr(wsf), nbf, T.S()))
+        fused.append(dwf)
+    assert torch.equal(fused[0], fused[1])
+    # the reductions-only call (dy = NULL) produces the same dgamma / dbeta as the full BatchNorm backward
+    dg, db = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
+    N.check(L.osi_bn_relu_maxpool_bwd(N.ptr(gpool), N.ptr(idx), N.ptr(y), N.ptr(mean), N.ptr(invstd), N.ptr(gamma), None, N.ptr(dg), N.ptr(db),
+                                      B, Ho, Wo, 64, N.ptr(ws), wsb, T.S()))
+    assert torch.equal(dg, dg0) and torch.equal(db, db0)
     # ---- fp64 evaluation of the same mathematics on the same decisions
     ib = idx.view(B, Hp, Wp, 16).cpu().numpy().view("uint8").reshape(B, Hp, Wp, 64)        # one byte per channel
     ib = torch.from_numpy(ib.astype("int64"))
@@ -228,8 +222,10 @@ def test_stem_backward_by_moments(cuda, B, H, W):
     c1, c2 = g64.view(M, 64).mean(0), (g64 * xh).view(M, 64).mean(0)
     dy64 = (g64 - c1 - xh * c2) * (gamma.cpu().double() * is64)
     dw64 = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 7, 7), dy64.permute(0, 3, 1, 2), 2, 3)
-    got, old = T.oihw(dw).cpu().double(), T.oihw(dw_direct).cpu().double()
+    old, fus = T.oihw(dw_direct).cpu().double(), T.oihw(fused[0]).cpu().double()
     rel = lambda a: float((a - dw64).norm() / dw64.norm())
-    print(f"B{B} {H}x{W}: rel-L2 vs fp64: by moments {rel(got):.2e}, materialised route {rel(old):.2e}")
-    assert rel(old) <= 5e-5 and rel(got) <= 5e-5
-    assert float((got - dw64).abs().max()) <= 2e-4 * float(dw64.abs().max())
+    print(f"B{B} {H}x{W}: rel-L2 vs fp64: fused loader {rel(fus):.2e}, materialised route {rel(old):.2e}")
+    assert rel(old) <= 5e-5 and rel(fus) <= 5e-5
+    # the fused loader evaluates the expressions of k_bn_bwd_apply<3> on the same operands (up to fma contraction)
+    assert float((fus - old).abs().max()) <= 2e-5 * float(dw64.abs().max())
+    assert float((fus - dw64).abs().max()) <= 2e-4 * float(dw64.abs().max())

@@ -42,6 +42,6 @@ for i in range(bwd0, n.value):
 rows = [(round(tt, 2), nm, "side" if sd else "main") for tt, nm, sd in ev[bwd0:] if nm in ("conv_dgrad", "conv_wgrad")]
 if os.environ.get("OSI_TIMELINE_FULL"):
     print(json.dumps(rows))
-sname = {0: "main", 1: "side", 2: "side2"}
+sname = {0: "main", 1: "side"}
 print("first forward ops:", [(round(tt, 3), nm, sname[sd]) for tt, nm, sd in ev[:14]])
 print("last ops of the step:", [(round(tt, 3), nm, sname[sd]) for tt, nm, sd in ev[-16:]])
