@@ -1404,12 +1404,18 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 3 : (WM * WN == 2 ?
 constexpr int W3_BKP = 32;                 // pixels per K tile
 constexpr int W3_LDA = 64 + 16;            // dY image row stride (floats): 16 consecutive cout x 4 pixels per ds_read_b32 -> two pixel rows
 constexpr int W3_LDB = 32 + 16;            //   land on disjoint bank halves when the stride is 16 mod 32
-template <int NWIN, bool XF>               // NWIN: window passes of 32 rows (2: W <= 15, 3: W <= 31, 5: W <= 63)
+// S2: stride 2 (pad 1, even H and W). The input splits into four parity sub-grids X_pq[b][i][j] = X[b][2 i + p][2 j + q], each with the
+// OUTPUT's geometry; tap (r, s) reads sub-grid (p, q) = (r != 1, s != 1) at (ho + di, wo + dj) with di = -1 for r = 0 and dj = -1 for
+// s = 0, else 0 — again a constant shift of the flattened (sub-grid) pixel index. The window is therefore four runs laid end to end
+// in LDS: ee (32 rows, tap (1,1)), eo (33: taps (1,0), (1,2)), oe (32 + Wo: (0,1), (2,1)), oo (33 + Wo: the four corner taps) =
+// 130 + 2 Wo rows of which each is ONE 128-byte piece of the tensor (its sub-grid pixel decomposed per row and run); the nine tap
+// offsets become nine row offsets into that layout and the validity mask only has to clear r = 0 at ho = 0 and s = 0 at wo = 0.
+template <int NWIN, bool XF, bool S2 = false>   // NWIN: window passes of 32 rows (2: W <= 15, 3: W <= 31, 5: W <= 63; S2: 5 or 6)
 __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accumulator + staging registers: 3 waves per SIMD, no spills
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn2 = wave >> 1, wc = wave & 1;
-    const int W = p.W, WIN = W3_BKP + 2 * W + 2;
+    const int W = p.W, WIN = S2 ? 130 + 2 * p.Wo : W3_BKP + 2 * W + 2;
     float* sA = smem;                                   // [32][W3_LDA]  dY rows of the run
     float* sB = sA + W3_BKP * W3_LDA;                   // [WIN][W3_LDB] X window
     uint32_t* sM = reinterpret_cast<uint32_t*>(sB + NWIN * 32 * W3_LDB);   // [32] tap-validity bits per pixel of the run
@@ -1439,6 +1445,20 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
     f32x4 ra[2], rb[NWIN];
     f32x4 xsc = {0, 0, 0, 0}, xsh = xsc;
     if (XF) { xsc = ld4(p.in_scale + c0 + b_c4 * 4); xsh = ld4(p.in_shift + c0 + b_c4 * 4); }
+    // S2: which sub-grid run this thread's window rows belong to and their offset from the run's first output pixel (fixed per thread)
+    int s2_off[NWIN], s2_pq[NWIN];
+    if (S2) {
+        const int Wo = p.Wo;
+#pragma unroll
+        for (int i = 0; i < NWIN; ++i) {
+            const int j = b_row + 32 * i;
+            if (j < 32) { s2_pq[i] = 0; s2_off[i] = j; }
+            else if (j < 65) { s2_pq[i] = 1; s2_off[i] = j - 32 - 1; }
+            else if (j < 97 + Wo) { s2_pq[i] = 2; s2_off[i] = j - 65 - Wo; }
+            else { s2_pq[i] = 3; s2_off[i] = j - (97 + Wo) - Wo - 1; }
+            if (j >= WIN) s2_pq[i] = -1;
+        }
+    }
 
     auto gload = [&](int t) {
         const int q0 = kbeg + t * W3_BKP;
@@ -1447,6 +1467,19 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
             const int q = q0 + a_row + 16 * i;
             ra[i] = bld4(rdy, q < kend ? (uint32_t)(((a_row + 16 * i) * p.Cout + n0 + a_c4 * 4) * 4) : OOB, (uint32_t)q0 * p.Cout * 4);
         }
+        if constexpr (S2) {
+#pragma unroll
+            for (int i = 0; i < NWIN; ++i) {
+                const int sq = q0 + s2_off[i];            // flattened pixel of the (p, q) sub-grid = an output-grid index
+                const bool in = s2_pq[i] >= 0 && sq >= 0 && sq < p.M;
+                const uint32_t sqq = in ? (uint32_t)sq : 0u;
+                const uint32_t b = fdiv(sqq, p.dHoWo);
+                const uint32_t rem = sqq - b * p.dHoWo.d;
+                const uint32_t hi = fdiv(rem, p.dWo), wi = rem - hi * p.dWo.d;
+                const uint32_t pix = (b * p.H + 2 * hi + (uint32_t)(s2_pq[i] >> 1)) * p.W + 2 * wi + (uint32_t)(s2_pq[i] & 1);
+                rb[i] = bld4(rx, in ? (pix * p.Cin + c0 + b_c4 * 4) * 4 : OOB, 0);
+            }
+        } else {
         const long wq0 = (long)q0 - W - 1;  // flattened input pixel of window row 0 (negative / past the end: range check -> zeros, masked anyway)
 #pragma unroll
         for (int i = 0; i < NWIN; ++i) {
@@ -1454,6 +1487,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
             const long wq = wq0 + j;
             const bool in = j < WIN && wq >= 0 && wq < (long)p.M;
             rb[i] = bld4(rx, in ? (uint32_t)((wq * p.Cin + c0 + b_c4 * 4) * 4) : OOB, 0);
+        }
         }
     };
     auto sstore = [&](int t) {
@@ -1475,8 +1509,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
                 const uint32_t b = fdiv((uint32_t)q, p.dHoWo);
                 const uint32_t rem = (uint32_t)q - b * p.dHoWo.d;
                 const int h = (int)fdiv(rem, p.dWo), w = (int)(rem - fdiv(rem, p.dWo) * p.dWo.d);
-                const uint32_t rowm = (h > 0 ? 1u : 0u) | 2u | (h < p.H - 1 ? 4u : 0u);     // r = 0, 1, 2
-                const uint32_t colm = (w > 0 ? 1u : 0u) | 2u | (w < p.W - 1 ? 4u : 0u);     // s = 0, 1, 2
+                // S2 (h, w = output row / column): only the top / left taps can leave the image (2 ho + 1 <= H - 1 for even H)
+                const uint32_t rowm = (h > 0 ? 1u : 0u) | 2u | ((S2 || h < p.H - 1) ? 4u : 0u);     // r = 0, 1, 2
+                const uint32_t colm = (w > 0 ? 1u : 0u) | 2u | ((S2 || w < p.W - 1) ? 4u : 0u);     // s = 0, 1, 2
 #pragma unroll
                 for (int r = 0; r < 3; ++r) if ((rowm >> r) & 1) bits |= colm << (3 * r);
             }
@@ -1485,6 +1520,21 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
     };
 
     const int l15 = lane & 15, lk = lane >> 4;
+    // row offset of tap (r, s) inside the window: stride 1: (r W + s); stride 2: the start of the tap's sub-grid run + its shift
+    int tapoff[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+            int o = r * W + sx;
+            if (S2) {
+                const int Wo = p.Wo;
+                const int pq = (r != 1 ? 2 : 0) + (sx != 1 ? 1 : 0);
+                const int base = pq == 0 ? 0 : pq == 1 ? 32 : pq == 2 ? 65 : 97 + Wo;
+                o = base + (r == 2 ? Wo : 0) + (sx == 2 ? 1 : 0);
+            }
+            tapoff[3 * r + sx] = o * W3_LDB;
+        }
     if (T > 0) {
         gload(0);
         sstore(0);
@@ -1501,9 +1551,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
                 o.m = sM[kp];
                 const float* bp = sB + kp * W3_LDB + 16 * wc + l15;
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) o.b[3 * r + s] = bp[(r * W + s) * W3_LDB];
+                for (int tp = 0; tp < 9; ++tp) o.b[tp] = bp[tapoff[tp]];
             };
             auto mma_ops = [&](const Ops& o) {
 #pragma unroll
@@ -1843,8 +1891,10 @@ static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
 
 // all-taps 3x3 weight gradient: eligibility, split plan, launch
 static bool wgrad3_ok(const osi_conv_desc* d) {
-    return g_osi_tuning.wgrad3 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 32 == 0 && d->Cout % 64 == 0 &&
-           d->W <= 63;
+    if (!g_osi_tuning.wgrad3 || d->R != 3 || d->S != 3 || d->pad != 1 || d->Cin % 32 || d->Cout % 64) return false;
+    if (d->stride == 1) return d->W <= 63;
+    // stride 2: four parity sub-grids of the input (even H and W), window of 130 + 2 Wo rows in at most six passes
+    return d->stride == 2 && g_osi_tuning.wgrad3 >= 2 && d->H % 2 == 0 && d->W % 2 == 0 && 130 + 2 * d->Wo <= 192;
 }
 static void plan_wgrad3(const osi_conv_desc* d, int& splits, int& kchunk) {
     const long cells = (long)(d->Cout / 64) * (d->Cin / 32);
@@ -1859,7 +1909,7 @@ static void plan_wgrad3(const osi_conv_desc* d, int& splits, int& kchunk) {
     long chunk = ((M + s - 1) / s + W3_BKP - 1) / W3_BKP * W3_BKP;
     splits = (int)((M + chunk - 1) / chunk); kchunk = (int)chunk;
 }
-template <int NWIN, bool XF>
+template <int NWIN, bool XF, bool S2 = false>
 static int launch_wgrad3_n(ConvP p, int splits, hipStream_t st) {
     p.MT = p.Cout / 64;
     const int ctiles = p.Cin / 32;
@@ -1867,14 +1917,15 @@ static int launch_wgrad3_n(ConvP p, int splits, hipStream_t st) {
     if (splits >= 8) { p.gkind = 0; p.gkeys = splits; p.ginner = p.MT * ctiles; }
     else { p.gkind = 3; p.gkeys = p.MT * ctiles * splits; p.ginner = 1; }
     const size_t smem = ((size_t)W3_BKP * W3_LDA + (size_t)NWIN * 32 * W3_LDB + 32) * sizeof(float);
-    if (int e = set_smem(k_conv_wgrad3<NWIN, XF>, smem)) return e;
+    if (int e = set_smem(k_conv_wgrad3<NWIN, XF, S2>, smem)) return e;
     const long grid = ((long)p.gkeys + 7) / 8 * 8 * p.ginner;
-    hipLaunchKernelGGL((k_conv_wgrad3<NWIN, XF>), dim3((unsigned)grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((k_conv_wgrad3<NWIN, XF, S2>), dim3((unsigned)grid), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
 template <bool XF>
 static int launch_wgrad3(const ConvP& p, int splits, hipStream_t st) {
+    if (p.stride == 2) return 130 + 2 * p.Wo <= 160 ? launch_wgrad3_n<5, XF, true>(p, splits, st) : launch_wgrad3_n<6, XF, true>(p, splits, st);
     const int win = W3_BKP + 2 * p.W + 2;
     if (win <= 64) return launch_wgrad3_n<2, XF>(p, splits, st);
     if (win <= 96) return launch_wgrad3_n<3, XF>(p, splits, st);

@@ -27,7 +27,7 @@ struct OsiTuning {
     int wgrad_nst;      // LDS stages of the weight-gradient kernel (1 or 2)
     int bn_grid;        // grid cap of the BatchNorm stream kernels
     int bn_single_p;    // BatchNorm statistics: row-tile partials merged by ONE launch up to this count, two-level above it
-    int wgrad3;         // 1 = 3x3 stride-1 weight gradients use the all-taps kernel (k_conv_wgrad3), 0 = the per-tap kernel
+    int wgrad3;         // 0 = per-tap kernel everywhere, 1 = 3x3 stride-1 weight gradients use the all-taps kernel (k_conv_wgrad3), 2 = stride 2 too
     int wgrad3_blocks;  // workgroups per launch the all-taps kernel's split-K plan aims for
     int fwd_wide, dgrad_wide;  // A/B: 64x128 forward / input-gradient tiles wherever the channel count allows (default 0: measured rule)
     int wgrad_group;    // weight-gradient block -> XCD mapping: 0 plain 2-D grid, 1 the R*S taps of a cell share an XCD, 2 whole K splits do

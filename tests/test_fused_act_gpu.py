@@ -222,7 +222,7 @@ def test_all_taps_3x3_weight_gradient(cuda, Cin, Cout, H, W, B, fused):
             N.check(L.osi_conv_wgrad(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(dw), N.ptr(ws), nb, T.S()))
         return dw
     v = ctypes.c_int()
-    assert L.osi_get_tuning(b"wgrad3", ctypes.byref(v)) == 0 and v.value == 1
+    assert L.osi_get_tuning(b"wgrad3", ctypes.byref(v)) == 0 and v.value == 2
     a, a2 = run(), run()
     per_tap = None
     if Cin % 64 == 0:                      # the per-tap kernel takes input channels in 64s only
@@ -230,11 +230,54 @@ def test_all_taps_3x3_weight_gradient(cuda, Cin, Cout, H, W, B, fused):
         try:
             per_tap = run()
         finally:
-            N.check(L.osi_set_tuning(b"wgrad3", 1))
+            N.check(L.osi_set_tuning(b"wgrad3", 2))
     act = torch.relu(x.double() * sc.double() + sh.double()) if fused else x.double()
     ref = torch.nn.grad.conv2d_weight(T.nchw(act), (Cout, Cin, 3, 3), T.nchw(dy.double()), 1, 1).permute(0, 2, 3, 1)
     scale = float(ref.abs().max()) + 1e-30
     Kp = B * H * W
+    assert torch.isfinite(a).all() and torch.equal(a, a2)
+    assert float((a.double() - ref).abs().max()) <= (2e-6 + 6e-8 * Kp ** 0.5) * scale + 1e-6
+    assert per_tap is None or float((a - per_tap).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,B", [(32, 64, 2, 2, 7), (64, 64, 4, 6, 5), (64, 128, 14, 14, 4), (128, 64, 28, 28, 3), (96, 64, 8, 30, 2),
+                                            (64, 64, 56, 56, 2), (64, 192, 6, 62, 3), (128, 128, 10, 2, 9)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_all_taps_3x3_stride2_weight_gradient(cuda, Cin, Cout, H, W, B, fused):
+    """The stride-2 form of k_conv_wgrad3 (the three stage-entry 3x3 convolutions of ResNet v1.5: four parity sub-grid runs per window,
+    five / six window passes): images of one output row / column, non-square images, ragged runs, batch boundaries inside a run, with and
+    without the fused input activation — against torch's conv2d_weight in fp64, against the per-tap kernel and against itself."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(Cin + Cout + H * 7 + W + 1)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 1.2).to(cuda)
+    d = N.ConvDesc.make(B, H, W, Cin, Cout, 3, 2, 1)
+    assert (d.Ho, d.Wo) == (H // 2, W // 2)
+    dy = torch.randn(B, d.Ho, d.Wo, Cout, generator=g).to(cuda)
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).to(cuda), (torch.randn(Cin, generator=g) * 0.6).to(cuda)
+
+    def run():
+        nb = L.osi_conv_wgrad_workspace(ctypes.byref(d))
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=cuda)
+        dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=cuda)
+        if fused:
+            N.check(L.osi_conv_wgrad_act(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(dw), N.ptr(ws), nb, T.S()))
+        else:
+            N.check(L.osi_conv_wgrad(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(dw), N.ptr(ws), nb, T.S()))
+        return dw
+    a, a2 = run(), run()
+    per_tap = None
+    if Cin % 64 == 0:
+        N.check(L.osi_set_tuning(b"wgrad3", 1))       # 1 = all-taps for stride 1 only: this layer takes the per-tap kernel
+        try:
+            per_tap = run()
+        finally:
+            N.check(L.osi_set_tuning(b"wgrad3", 2))
+    act = torch.relu(x.double() * sc.double() + sh.double()) if fused else x.double()
+    ref = torch.nn.grad.conv2d_weight(T.nchw(act), (Cout, Cin, 3, 3), T.nchw(dy.double()), 2, 1).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max()) + 1e-30
+    Kp = B * d.Ho * d.Wo
     assert torch.isfinite(a).all() and torch.equal(a, a2)
     assert float((a.double() - ref).abs().max()) <= (2e-6 + 6e-8 * Kp ** 0.5) * scale + 1e-6
     assert per_tap is None or float((a - per_tap).abs().max()) <= 2e-5 * scale
