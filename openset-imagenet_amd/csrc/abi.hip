@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 32, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*stem_direct*/ 1};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*stem_direct*/ 1};
 
 namespace {
 int* tuning_slot(const char* name) {
@@ -26,7 +26,7 @@ int* tuning_slot(const char* name) {
 }  // namespace
 
 extern "C" {
-int osi_abi_version(void) { return 2; }
+int osi_abi_version(void) { return 3; }   // 3: debug gate read-out, executor geometry, direct / fused stem kernels, const crop table
 int osi_set_tuning(const char* name, int value) {
     int* s = tuning_slot(name);
     if (!s) return OSI_ERR_ARG;
