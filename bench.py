@@ -68,34 +68,64 @@ def _cpu_leg(C, p_neg, loss, steps, B):
         _, _, _, grads = R.forward_backward(sd, x, y, fn)
         R.adam_step(sd, grads, state, lr=1e-3)
         times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu baseline ({loss}, C={C}) step {i}/{steps}: {times[-1]:.2f} s on {torch.get_num_threads()} threads", file=sys.stderr, flush=True)
+        if times[-1] > 60 and i >= 1:      # a host this slow gets one timed step: the default run must end within minutes
+            break
     best = min(times[1:])
     return best, B / best
 
 
-def cpu_baseline(C, p_neg, steps=2, B=32):
+def usable_cpus():
+    """How many CPUs' worth of time this process can get, and every limit that went into it."""
+    n = os.cpu_count() or 1
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else n
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = max(1, -(-int(txt[0]) // int(txt[1])))
+            elif int(txt[0]) > 0:
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                quota = max(1, -(-int(txt[0]) // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    gpus = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    share = 16 * max(1, gpus)
+    return {"threads": max(1, min(n, aff, quota or n, share)), "host_cpu_count": n, "affinity_cpus": aff, "cgroup_cpu_quota": quota,
+            "lease_share_16_per_gpu": share}
+
+
+def cpu_baseline(C, p_neg, steps=5, B=32):
     """The CPU oracle (torch-CPU restatement of the reference path) timed on this host's cores, the two legs SURVEY.md §8(d) names:
     the GPU workload's own loss at B = 32 (`value`) and BASELINE.json config 1 (Protocol 1, C = 116, softmax cross-entropy, B = 32)."""
-    # SURVEY.md §8(d): torch.set_num_threads(os.cpu_count()) — bounded by the CPUs this process may actually run on (a GPU box
-    # hands each lease a share of the host), because threads beyond the affinity mask only oversubscribe the cores
+    # SURVEY.md §8(d) says torch.set_num_threads(os.cpu_count()). On a GPU box that is wrong by an order of magnitude: the host has 256
+    # logical CPUs but a one-GPU lease owns a share of them (16 per GPU on this pool), and 128-256 compute threads on 16 CPUs' worth of
+    # time make every oneDNN primitive crawl (round 2: 10.2 s per step with torch's default 128 threads, against 3.7-5.3 s on 8 cores
+    # in the build container; 256 threads did not finish a step in 7 minutes). The thread count is therefore the CPU time this process
+    # can actually get: min(os.cpu_count(), affinity mask, cgroup CPU quota, 16 per visible GPU).
     default_threads = torch.get_num_threads()
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    want = max(1, min(os.cpu_count() or 1, usable))
+    limits = usable_cpus()
+    want = limits["threads"]
     torch.set_num_threads(want)
     try:
         best, ips = _cpu_leg(C, p_neg, "entropic", steps, B)
-        best1, ips1 = _cpu_leg(116, 0.0, "softmax", 1, B)
+        best1, ips1 = _cpu_leg(116, 0.0, "softmax", 3, B)
         used = torch.get_num_threads()
     finally:
         torch.set_num_threads(default_threads)
     return {"value": round(ips, 3), "unit": "images/sec", "cores": used, "kind": "port",
-            "threads": {"used": used, "set_num_threads_applied": True, "requested": want, "torch_default": default_threads,
-                        "host_cpu_count": os.cpu_count(), "affinity_cpus": usable,
-                        "rule": "torch.set_num_threads(min(os.cpu_count(), CPUs in this process's affinity mask)) — SURVEY.md §8(d)"},
-            "sample": f"{steps} timed steps (after 1 warm-up) of batch {B}, same shapes/loss as the GPU workload, best step {best:.2f} s; "
+            "threads": {"used": used, "set_num_threads_applied": True, "set_to_os_cpu_count": want == (os.cpu_count() or 0),
+                        "torch_default": default_threads, **limits,
+                        "rule": "torch.set_num_threads(min(os.cpu_count(), affinity mask, cgroup CPU quota, 16 per visible GPU)): the CPUs this "
+                                "process can actually get; SURVEY.md §8(d)'s plain os.cpu_count() oversubscribes a one-GPU lease 16x"},
+            "sample": f"best of {steps} timed steps (after 1 warm-up) of batch {B}, same shapes/loss as the GPU workload, best step {best:.2f} s; "
                       f"oracle/resnet50_oracle.py (torch-CPU fp32 restatement; the reference package itself is not importable offline)",
             "config1_protocol1_softmax_b32": {"value": round(ips1, 3), "unit": "images/sec",
-                                              "sample": f"1 timed step (after 1 warm-up, i.e. a single measurement, not a best-of) of batch {B}, "
-                                                        f"C = 116, softmax cross-entropy, Adam; step {best1:.2f} s (BASELINE.json configs[0])"},
+                                              "sample": f"best of 3 timed steps (after 1 warm-up) of batch {B}, C = 116, softmax "
+                                                        f"cross-entropy, Adam; step {best1:.2f} s (BASELINE.json configs[0])"},
             "host_cpu_count": os.cpu_count()}
 
 
