@@ -94,6 +94,14 @@ typedef struct {
     size_t partials_bytes;  /* >= osi_conv_dgrad_fused_workspace(d) */
     const float* scale0;    /* alternative gate when relu_mask == NULL: the producer's activation relu(y0 * scale0 + shift0) was */
     const float* shift0;    /* never stored (osi_conv_fwd_act consumed y0 directly), so the gate is recomputed: on where > 0 */
+    /* Pool mode (ABI 3; stride-1 convs, relu_mask = scale0 = NULL): this conv's input is the output of the stem's fused
+     * bn -> ReLU -> max-pool 3x3 / 2 (osi_bn_relu_maxpool_fwd), so dx is the gradient w.r.t. the POOLED activation. pool_idx = that
+     * kernel's arg-max bytes; y0 / mean0 / invstd0 describe the BatchNorm BEFORE the pool, y0 being [B][pool_H][pool_W][Cin]. dx is
+     * written unmasked; the partials become the BatchNorm-backward reductions of the max-pool-scattered, ReLU-gated gradient
+     * (sum g and sum g * xhat(arg-max pixel) per row tile): bn1's dgamma / dbeta need no pass over the 112 x 112 tensor of their own.
+     * Finish them with osi_bn_backward_reduce. */
+    const void* pool_idx;
+    int pool_H, pool_W;
 } osi_dgrad_fusion;
 size_t osi_conv_dgrad_fused_workspace(const osi_conv_desc* d);
 int osi_conv_dgrad_fused(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,
@@ -191,6 +199,11 @@ int osi_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, int B, int
  *        "window maximum > 0" (the ReLU gate of the pixel the gradient will return to).
  *   bwd: gpool = dJ/dpooled -> dgamma, dbeta and dy = BatchNorm backward of the pool-scattered, ReLU-gated gradient, gathered on
  *        the fly (no [B][H][W][C] gradient tensor). ws: osi_bn_backward_workspace(B*H*W, C) bytes. */
+/* The reduction half of osi_bn_backward_fused alone: merges per-row-tile partials (psum_g, psum_gx: [P][C], e.g. from a pool-mode
+ * osi_conv_dgrad_fused) into dgamma / dbeta. M = elements per channel of the BatchNorm (c1 = dbeta / M, c2 = dgamma / M are left in ws
+ * for callers that want them). ws: osi_bn_backward_workspace(M, C) bytes. */
+int osi_bn_backward_reduce(const float* psum_g, const float* psum_gx, int P, float* dgamma, float* dbeta, int M, int C, void* ws,
+                           size_t ws_bytes, osi_stream_t stream);
 int osi_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* pooled, void* idx, int B, int H, int W,
                             int C, osi_stream_t stream);
 int osi_bn_relu_maxpool_bwd(const float* gpool, const void* idx, const float* y, const float* mean, const float* invstd,

@@ -621,6 +621,27 @@ int osi_bn_backward_fused(const float* g, const float* y, const float* mean, con
     return OSI_OK;
 }
 
+int osi_bn_backward_reduce(const float* psum_g, const float* psum_gx, int P, float* dgamma, float* dbeta, int M, int C, void* ws,
+                           size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(psum_g && psum_gx && dgamma && dbeta && ws && M > 0 && C > 0 && P > 0);
+    int S = osi_cdiv(P, 64);
+    if (S > OSI_BN_GROUPS) S = OSI_BN_GROUPS;
+    const int Pc = osi_cdiv(P, S);
+    S = osi_cdiv(P, Pc);
+    OSI_REQUIRE(ws_bytes >= ((size_t)2 * S * C + 2 * (size_t)C) * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float* gb = (float*)ws;
+    float* gg = gb + (size_t)S * C;
+    float* c1 = gg + (size_t)S * C;
+    float* c2 = c1 + C;
+    hipLaunchKernelGGL(k_colsum2_group, dim3(osi_cdiv(C, 16), S), dim3(NT), 0, st, psum_g, psum_gx, P, Pc, C, S, gb, gg);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, (const float*)gb, (const float*)gg, S, M, C, dgamma,
+                       dbeta, c1, c2);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
 int osi_bn_relu_maxpool_bwd(const float* gpool, const void* idx, const float* y, const float* mean, const float* invstd,
                             const float* gamma, float* dy, float* dgamma, float* dbeta, int B, int H, int W, int C, void* ws,
                             size_t ws_bytes, osi_stream_t stream) {

@@ -53,6 +53,8 @@ struct ConvP {
     const float* ey1;
     const float *emean0, *einv0, *emean1, *einv1;  // batch mean / invstd of the consumer BatchNorm(s): xhat = (y - mean) * invstd
     const float *escale0, *eshift0;                // ReLU gate recomputed from ey0 (no bitmask): on where ey0 * scale + shift > 0
+    const uint32_t* epool;                         // pool mode: arg-max bytes of the max-pool whose output this conv reads; ey0 is the
+    int epH, epW;                                  // pre-pool tensor [B][epH][epW][Cin] (osi_dgrad_fusion.pool_idx)
     float* esum;
     int eP;
     // wgrad only
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(256, SRC == 2 ? 2 : 3) void k_stem_outer(StemOuterP
 // partial sums of the consumer layer(s). `rd(row, c4)` returns the accumulated float4 of tile row `row`, channel quad `c4`: the
 // convolution kernel reads its LDS-transposed accumulators, the fix-up pass of a K-split tail sums the tile's slab entries. One
 // code path for both keeps their results identical in form (same gates, same reduction order inside the tile).
-template <bool FUSED, typename RD>
+template <bool FUSED, bool POOL, typename RD>
 __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, int cls, int mt, int m0, int n0, int Mc, int st, int ph,
                                                  int pw, const FastDiv& dHW, const FastDiv& dW, RD rd) {
     constexpr int BN = 64;
@@ -890,6 +892,22 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
                 v[2] = (w23.x >> bit) & 1 ? v[2] : 0.f; v[3] = (w23.y >> bit) & 1 ? v[3] : 0.f;
             }
             f32x4 y0v = {0, 0, 0, 0};
+            if constexpr (POOL) {
+                // dx is the gradient w.r.t. a max-pooled activation: the BatchNorm-backward reductions of the layer BEFORE the pool
+                // see this value at the window's arg-max pixel, gated by the window's ReLU (bit 7): sum g, sum g * xhat(arg-max)
+                const uint32_t bb = fdiv(pix, dHW), rem = pix - bb * dHW.d, ho = fdiv(rem, dW), wo = rem - ho * dW.d;
+                const uint32_t idw = p.epool[off >> 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t byte = (idw >> (8 * e)) & 0xffu, t = byte & 0x7fu, r = t / 3u, sx = t - 3u * r;
+                    const uint32_t apix = (bb * p.epH + 2u * ho - 1u + r) * p.epW + 2u * wo - 1u + sx;
+                    const float gv = (byte & 0x80u) ? v[e] : 0.f;
+                    sg[e] += gv;
+                    s0[e] += (gv * (p.ey0[(size_t)apix * p.Cin + col + e] - mu0[e])) * is0[e];
+                }
+                *reinterpret_cast<f32x4*>(p.y + off) = v;
+                continue;
+            }
             if (p.escale0 || p.esum) y0v = ld4(p.ey0 + off);
             if (p.escale0) {   // the producer's activation was never stored: its ReLU gate is recomputed from the pre-BN tensor
 #pragma unroll               // with the very expression (one fma) the forward loader used
@@ -938,7 +956,9 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
 // blockIdx.y = class. GEMM N = Cin, K = (taps of the class) x Cout.
 // ======================================================================================================
 // KS: the launch carries a K-split tail (stride 1 only; see tile_of_block_split), its own instantiation like k_conv_fwd's
-template <int WM, int WN, int NST, bool FUSED, bool KS = false>
+// POOL: pool-mode reductions in the epilogue (osi_dgrad_fusion.pool_idx) — one launch per step, its own instantiation so that the
+// workhorse keeps its 8 waves per SIMD
+template <int WM, int WN, int NST, bool FUSED, bool KS = false, bool POOL = false>
 __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0) {
     static_assert(!KS || (WM == 1 && WN == 1 && NST == 1), "the K-split tail is built for the single-buffered 64x64 tile");
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -1091,7 +1111,7 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
             }
             return;
         }
-        dgrad_epilogue64<FUSED>(p, smem, cls, mt, m0, n0, Mc, st, ph, pw, dHW, dW,
+        dgrad_epilogue64<FUSED, POOL>(p, smem, cls, mt, m0, n0, Mc, st, ph, pw, dHW, dW,
                                 [&](int rl, int c4) { return *reinterpret_cast<const f32x4*>(tile + rl * LDT + c4 * 4); });
         return;
     }
@@ -1657,7 +1677,7 @@ __global__ __launch_bounds__(256) void k_conv_dgrad_tail_fixup(ConvP p) {
     const int mt = p.MT1 + tile / p.NT, nt = tile - (tile / p.NT) * p.NT;
     const float* src = p.ks_slab + (size_t)tile * p.ks_S * 4096;
     const int nsp = p.ks_S;
-    dgrad_epilogue64<FUSED>(p, red, 0, mt, mt * 64, nt * 64, p.B * p.H * p.W, 1, 0, 0, p.cHW[0], p.cW[0], [&](int rl, int c4) {
+    dgrad_epilogue64<FUSED, false>(p, red, 0, mt, mt * 64, nt * 64, p.B * p.H * p.W, 1, 0, 0, p.cHW[0], p.cW[0], [&](int rl, int c4) {
         f32x4 a = ld4(src + rl * 64 + c4 * 4);
         for (int sp = 1; sp < nsp; ++sp) a += ld4(src + (size_t)sp * 4096 + rl * 64 + c4 * 4);
         return a;
@@ -1806,7 +1826,7 @@ static int launch_fwd(ConvP p, hipStream_t st) {
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
-template <int WM, int WN, int NST, bool FUSED>
+template <int WM, int WN, int NST, bool FUSED, bool POOL = false>
 static int launch_dgrad_impl(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int s = p.stride;
@@ -1821,9 +1841,9 @@ static int launch_dgrad_impl(ConvP p, hipStream_t st) {
     p.MT = osi_cdiv((long)p.B * Hc * Wc, BM); p.NT = p.Cin / BN;
     size_t smem = 2 * (size_t)(BM * LDR + BK * (BN + 4)) * sizeof(float);
     smem = smem / 2 * NST;
-    if (int e = set_smem(k_conv_dgrad<WM, WN, NST, FUSED>, smem)) return e;
+    if (int e = set_smem(k_conv_dgrad<WM, WN, NST, FUSED, false, POOL>, smem)) return e;
     int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
-    hipLaunchKernelGGL((k_conv_dgrad<WM, WN, NST, FUSED>), dim3(grid, s * s), dim3(256), smem, st, p, Hc, Wc);
+    hipLaunchKernelGGL((k_conv_dgrad<WM, WN, NST, FUSED, false, POOL>), dim3(grid, s * s), dim3(256), smem, st, p, Hc, Wc);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
@@ -1850,6 +1870,7 @@ static int launch_dgrad(ConvP p, hipStream_t st) {
     // the fused epilogue (mask / BatchNorm reductions) is its own instantiation so that plain launches keep the small one
     if (p.ebits || p.esum || p.escale0) {
         if (NST != 1 || WM != 1) return OSI_ERR_ARG;   // fusion is built for the single-buffered 64-row tiles the executor uses
+        if (p.epool) return WN == 1 ? launch_dgrad_impl<1, 1, 1, true, true>(p, st) : OSI_ERR_ARG;
         return launch_dgrad_impl<1, WN, 1, true>(p, st);
     }
     return launch_dgrad_impl<WM, WN, NST, false>(p, st);
@@ -2157,7 +2178,13 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     // on every ResNet-50 shape (the dgrad class went 12.1 -> 11.0 ms per step against the 64x128 rule used before).
     if (tile == OSI_TILE_AUTO) tile = (g_osi_tuning.dgrad_wide && d->Cin % 128 == 0) ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
     if (f) {
-        OSI_REQUIRE(f->relu_mask || f->scale0 || !f->partials);
+        OSI_REQUIRE(f->relu_mask || f->scale0 || !f->partials || f->pool_idx);
+        if (f->pool_idx) {   // pool mode: stride-1 conv behind the stem's max-pool, reductions only (no gate on dx), one consumer
+            OSI_REQUIRE(!f->relu_mask && !f->scale0 && f->partials && !f->y1 && d->stride == 1 && f->pool_H > 0 && f->pool_W > 0);
+            OSI_REQUIRE((f->pool_H + 2 - 3) / 2 + 1 == d->H && (f->pool_W + 2 - 3) / 2 + 1 == d->W);
+            OSI_REQUIRE(tile == OSI_TILE_AUTO || tile == OSI_TILE_64x64_S1);
+            p.epool = (const uint32_t*)f->pool_idx; p.epH = f->pool_H; p.epW = f->pool_W;
+        }
         OSI_REQUIRE(!f->scale0 || (!f->relu_mask && f->shift0 && f->y0));   // one gate source: the bitmask, or y0 * scale0 + shift0 > 0
         p.ebits = (const unsigned long long*)f->relu_mask;
         p.escale0 = f->scale0; p.eshift0 = f->shift0;
@@ -2173,7 +2200,7 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
             *P = p.eP;
             // ragged last round split along K when the caller's workspace has room for the slab behind the partial sums
             const TailPlan tp = dgrad_tail_plan(d);
-            if (tile == OSI_TILE_64x64_S1 && tp.S > 1 && f->partials_bytes >= (dgrad_partial_floats(d) + tail_slab_floats(tp)) * sizeof(float))
+            if (!f->pool_idx && tile == OSI_TILE_64x64_S1 && tp.S > 1 && f->partials_bytes >= (dgrad_partial_floats(d) + tail_slab_floats(tp)) * sizeof(float))
                 return launch_dgrad_split<true>(p, tp, f->partials + dgrad_partial_floats(d), st);
         }
     }

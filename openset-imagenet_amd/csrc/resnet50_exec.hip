@@ -151,6 +151,8 @@ struct osi_resnet50 {
     bool side_prio_normal = false;   // side stream at default instead of lowest priority (read when the stream is created)
     const float* x4_ext = nullptr;   // external NHWC4 input bound by osi_resnet50_bind_input_nhwc4 (consumed by one forward)
     const float* x4_cur = nullptr;   // input of the step in flight (forward sets it, the stem weight gradient reads it)
+    bool stem_pool_stats = true;     // option "stem_pool_stats": bn1's backward reductions come out of layer1.0.conv1's dgrad epilogue
+    int stem_stats_P = 0;            // > 0: bn1's backward partial sums wait in dg_ws (left by the pool-mode epilogue of layer1.0.conv1's dgrad)
     bool stem_fused = true;          // option "stem_fused": conv1's weight gradient builds dY in its operand loader (osi_stem_wgrad_fused)
                                      // behind the BatchNorm reductions: no 112x112x64 gradient tensor, no apply pass (step -0.15 ms)
     bool stagger = false;            // option "stagger": a weight gradient starts when the input gradient of the SAME layer has finished
@@ -723,7 +725,26 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
         n->cur_grad = dxn;
         n->go_fused = true;
     } else {
-        OSI_TRY(dgrad_plain(n, &c1.d, S(t3), params + c1.w_off, S(dxbase), 1, st));
+        // first block: its input is the stem's max-pooled activation. With the fused stem tail the epilogue of this LAST input gradient
+        // (it completes the gradient w.r.t. the pooled activation) also emits bn1's backward reductions through the arg-max bytes, so the
+        // stem needs no reduction pass over its 112 x 112 tensor (pool mode of osi_conv_dgrad_fused)
+        Conv& c0 = n->convs[0];
+        n->stem_stats_P = 0;
+        if (n->stem_fused && n->stem_pool_stats && osi_stem_wgrad_fused_workspace(&c0.d) > 0) {
+            BN& b0 = n->bns[c0.bn];
+            osi_dgrad_fusion f{};
+            f.y0 = ws + c0.y; f.mean0 = ws + b0.mean; f.invstd0 = ws + b0.invstd;
+            f.partials = ws + n->dg_ws; f.partials_bytes = n->dg_ws_bytes;
+            f.pool_idx = ws + n->pool_idx; f.pool_H = n->Hs; f.pool_W = n->Ws;
+            int P = 0;
+            OSI_TRY(before_dgrad(n, st));
+            OSI_TRY(osi_conv_dgrad_fused(&c1.d, S(t3), params + c1.w_off, S(dxbase), S(dxbase), &f, OSI_TILE_AUTO, &P, st));
+            n->stem_stats_P = P;
+            OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, st));
+            OSI_TRY(flush_wgrad(n, st));
+        } else {
+            OSI_TRY(dgrad_plain(n, &c1.d, S(t3), params + c1.w_off, S(dxbase), 1, st));
+        }
         n->cur_grad = dxbase;
         n->go_fused = false;
     }
@@ -783,8 +804,16 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
                 // reductions of bn1's backward (dgamma, dbeta) on the main stream, then the weight gradient with the max-pool scatter,
                 // ReLU gate and BatchNorm backward applied inside its operand loader: the 112x112x64 gradient is never written
                 n->give(t);
-                OSI_TRY(osi_bn_relu_maxpool_bwd(S(go), ws + n->pool_idx, ws + c0.y, ws + b0.mean, ws + b0.invstd, params + b0.g_off, nullptr,
-                                                grads + b0.g_off, grads + b0.b_off, n->B, n->Hs, n->Ws, 64, ws + n->bn_ws, n->bn_ws_bytes, st));
+                if (n->stem_stats_P > 0) {   // the reductions arrived with the last input gradient: two tiny merge launches
+                    const float* psum_g = ws + n->dg_ws;
+                    OSI_TRY(osi_bn_backward_reduce(psum_g, psum_g + (size_t)n->stem_stats_P * 64, n->stem_stats_P, grads + b0.g_off,
+                                                   grads + b0.b_off, n->B * n->Hs * n->Ws, 64, ws + n->bn_ws, n->bn_ws_bytes, st));
+                    n->stem_stats_P = 0;
+                } else {
+                    OSI_TRY(osi_bn_relu_maxpool_bwd(S(go), ws + n->pool_idx, ws + c0.y, ws + b0.mean, ws + b0.invstd, params + b0.g_off,
+                                                    nullptr, grads + b0.g_off, grads + b0.b_off, n->B, n->Hs, n->Ws, 64, ws + n->bn_ws,
+                                                    n->bn_ws_bytes, st));
+                }
                 OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
                 const bool async = n->async_wgrad();
                 hipStream_t gs = st;
@@ -924,6 +953,7 @@ int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
     else if (!strcmp(name, "stagger")) n->stagger = value != 0;
     else if (!strcmp(name, "fwd_recompute")) n->fwd_recompute = value != 0;
     else if (!strcmp(name, "stem_fused")) n->stem_fused = value != 0;
+    else if (!strcmp(name, "stem_pool_stats")) n->stem_pool_stats = value != 0;
     else if (!strcmp(name, "side_priority_normal")) {
         if (n->side) return OSI_ERR_STATE;   // the side stream already exists with the other priority
         n->side_prio_normal = value != 0;

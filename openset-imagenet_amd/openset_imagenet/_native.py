@@ -48,6 +48,7 @@ _SIGS = {
     "osi_conv_dgrad": (c_int, [_PD, P, P, P, c_int, c_int, P]),
     "osi_conv_dgrad_fused_workspace": (c_size_t, [_PD]),
     "osi_conv_dgrad_fused": (c_int, [_PD, P, P, P, P, P, c_int, POINTER(c_int), P]),
+    "osi_bn_backward_reduce": (c_int, [P, P, c_int, P, P, c_int, c_int, P, c_size_t, P]),
     "osi_bn_backward_fused": (c_int, [P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P, c_size_t, P]),
     "osi_conv_wgrad_workspace": (c_size_t, [_PD]),
     "osi_conv_wgrad": (c_int, [_PD, P, P, P, P, c_size_t, P]),

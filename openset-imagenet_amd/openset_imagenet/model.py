@@ -42,7 +42,9 @@ def debug_options_from_env():
         OSI_STAGGER=1         stagger 1           weight gradients only beside BatchNorm-backward kernels, never beside an input gradient
         OSI_SIDE_PRIO=n       side_priority_normal 1
         OSI_STEM_FUSED=0      stem_fused 0        conv1's weight gradient from a materialised 112x112x64 gradient (BatchNorm apply pass)
-        OSI_FUSED_ACT=0       fused_act 0         in-block activations materialised by a BatchNorm-apply pass instead of in the loaders"""
+        OSI_STEM_POOL_STATS=0 stem_pool_stats 0   bn1's backward reductions by their own pass instead of layer1.0.conv1's dgrad epilogue
+    (There is no switch for round 2's fused in-block activations: the unfused executor path no longer exists; its price on one box is the
+    three-way A/B of the committed round-1 / round-2 / current trees, profiles/r03_ab_rounds.txt.)"""
     env = os.environ
     out = {}
     if env.get("OSI_NO_OVERLAP"):
@@ -57,8 +59,8 @@ def debug_options_from_env():
         out["side_priority_normal"] = 1
     if env.get("OSI_STEM_FUSED") == "0":
         out["stem_fused"] = 0
-    if env.get("OSI_FUSED_ACT") == "0":
-        out["fused_act"] = 0
+    if env.get("OSI_STEM_POOL_STATS") == "0":
+        out["stem_pool_stats"] = 0
     return out
 
 

@@ -229,3 +229,66 @@ def test_stem_weight_gradient_with_fused_tail(cuda, B, H, W):
     # the fused loader evaluates the expressions of k_bn_bwd_apply<3> on the same operands (up to fma contraction)
     assert float((fus - old).abs().max()) <= 2e-5 * float(dw64.abs().max())
     assert float((fus - dw64).abs().max()) <= 2e-4 * float(dw64.abs().max())
+
+
+@pytest.mark.parametrize("B,Hs,Ws,Cout", [(2, 16, 16, 64), (3, 24, 40, 256), (4, 112, 112, 64)])
+def test_pool_mode_dgrad_emits_the_stem_batchnorm_reductions(cuda, B, Hs, Ws, Cout):
+    """Pool mode of osi_conv_dgrad_fused (the input gradient of layer1.0.conv1, whose input is the stem's max-pooled activation): dx is
+    the plain input gradient + addend, and the per-row-tile partials finished by osi_bn_backward_reduce are bn1's dgamma / dbeta —
+    equal (to fp32 summation noise) to the reductions osi_bn_relu_maxpool_bwd computes by scanning the 112 x 112 tensor."""
+    import ctypes
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+
+    class Fusion(ctypes.Structure):
+        _fields_ = [("relu_mask", ctypes.c_void_p), ("y0", ctypes.c_void_p), ("mean0", ctypes.c_void_p), ("invstd0", ctypes.c_void_p),
+                    ("y1", ctypes.c_void_p), ("mean1", ctypes.c_void_p), ("invstd1", ctypes.c_void_p), ("partials", ctypes.c_void_p),
+                    ("partials_bytes", ctypes.c_size_t), ("scale0", ctypes.c_void_p), ("shift0", ctypes.c_void_p),
+                    ("pool_idx", ctypes.c_void_p), ("pool_H", ctypes.c_int), ("pool_W", ctypes.c_int)]
+    g = torch.Generator().manual_seed(B + Hs + Ws + Cout)
+    C = 64
+    Hp, Wp = (Hs + 2 - 3) // 2 + 1, (Ws + 2 - 3) // 2 + 1
+    Ms = B * Hs * Ws
+    y = (torch.randn(B, Hs, Ws, C, generator=g) * 1.5 + 0.2).to(cuda)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(cuda), (torch.randn(C, generator=g) * 0.3).to(cuda)
+    mean = y.view(Ms, C).mean(0)
+    invstd = 1 / torch.sqrt(y.view(Ms, C).var(0, unbiased=False) + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    pooled = torch.empty(B, Hp, Wp, C, device=cuda)
+    idx = torch.zeros(B * Hp * Wp * (C // 4), dtype=torch.int32, device=cuda)
+    N.check(L.osi_bn_relu_maxpool_fwd(N.ptr(y), N.ptr(scale), N.ptr(shift), N.ptr(pooled), N.ptr(idx), B, Hs, Ws, C, T.S()))
+    # the conv behind the pool: 1x1, C -> Cout; its input gradient (+ an addend: the shortcut branch's gradient) is dJ/dpooled
+    d = N.ConvDesc.make(B, Hp, Wp, C, Cout, 1, 1, 0)
+    dy = torch.randn(B, Hp, Wp, Cout, generator=g).to(cuda)
+    w = (torch.randn(Cout, 1, 1, C, generator=g) / Cout ** 0.5).to(cuda)
+    addend = torch.randn(B, Hp, Wp, C, generator=g).to(cuda)
+    ref_dx = addend.clone()
+    N.check(L.osi_conv_dgrad(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(ref_dx), 1, 0, T.S()))
+    pb = L.osi_conv_dgrad_fused_workspace(ctypes.byref(d))
+    parts = torch.full((pb // 4,), float("nan"), device=cuda)
+    f = Fusion(None, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), None, None, None, parts.data_ptr(), pb, None, None, idx.data_ptr(), Hs, Ws)
+    dx = addend.clone()
+    P = ctypes.c_int()
+    N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(dx), N.ptr(dx), ctypes.byref(f), 0, ctypes.byref(P), T.S()))
+    assert torch.equal(dx, ref_dx), "pool mode leaves the input gradient itself untouched (same kernel, same bits)"
+    wsb = L.osi_bn_backward_workspace(Ms, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    dg, db = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    N.check(L.osi_bn_backward_reduce(parts.data_ptr(), parts.data_ptr() + 4 * P.value * C, P.value, N.ptr(dg), N.ptr(db), Ms, C, N.ptr(ws), wsb, T.S()))
+    dg0, db0 = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    N.check(L.osi_bn_relu_maxpool_bwd(N.ptr(dx), N.ptr(idx), N.ptr(y), N.ptr(mean), N.ptr(invstd), N.ptr(gamma), None, N.ptr(dg0), N.ptr(db0),
+                                      B, Hs, Ws, C, N.ptr(ws), wsb, T.S()))
+    # fp64 truth through the arg-max bytes
+    ib = torch.from_numpy(idx.view(B, Hp, Wp, C // 4).cpu().numpy().view("uint8").reshape(B, Hp, Wp, C).astype("int64"))
+    gate, tap = ib >= 128, ib % 128
+    hh = (torch.arange(Hp).view(1, Hp, 1, 1) * 2 - 1 + tap // 3).clamp(0, Hs - 1)
+    ww = (torch.arange(Wp).view(1, 1, Wp, 1) * 2 - 1 + tap % 3).clamp(0, Ws - 1)
+    bidx = torch.arange(B).view(B, 1, 1, 1).expand_as(ib)
+    cidx = torch.arange(C).view(1, 1, 1, C).expand_as(ib)
+    xh = ((y.cpu().double() - mean.cpu().double()) * invstd.cpu().double())[bidx, hh, ww, cidx]
+    gq = torch.where(gate, dx.cpu().double(), torch.zeros(1, dtype=torch.float64))
+    db64, dg64 = gq.sum(dim=(0, 1, 2)), (gq * xh).sum(dim=(0, 1, 2))
+    sc = float(dg64.abs().max()) + float(db64.abs().max())
+    assert float((dg.cpu().double() - dg64).abs().max()) <= 2e-5 * sc and float((db.cpu().double() - db64).abs().max()) <= 2e-5 * sc
+    assert float((dg0.cpu().double() - dg64).abs().max()) <= 2e-5 * sc and float((db0.cpu().double() - db64).abs().max()) <= 2e-5 * sc
