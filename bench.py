@@ -188,19 +188,31 @@ def rccl_proof(model, net, backend, world, local, dev):
              "pci_device_id": getattr(props, "pci_device_id", None), "name": props.name, "pid": os.getpid()}
     everyone = [None] * world
     dist.all_gather_object(everyone, ident)
-    key = lambda d: d["uuid"] if d["uuid"] and set(d["uuid"]) - set("0-") else (d["pci_bus_id"], d["pci_device_id"], d["device_index"])
-    distinct = len({key(d) for d in everyone})
+    # Two ranks provably share a device when an INFORMATIVE identifier coincides: the PCI bus id, or a uuid that is not all zeros. The
+    # device index alone proves nothing either way (a launcher may give every rank its own visibility mask, all index 0), so it only
+    # counts when nothing better exists. A shared device under RCCL is an error; ambiguous evidence is reported, never fatal.
+    def informative(d):
+        if d["pci_bus_id"] is not None:
+            return "pci_bus_id", (d["pci_bus_id"], d["pci_device_id"])
+        if d["uuid"] and set(d["uuid"]) - set("0-"):
+            return "uuid", d["uuid"]
+        return "device_index", d["device_index"]
+    kinds = {informative(d)[0] for d in everyone}
+    evidence = kinds.pop() if len(kinds) == 1 else "mixed"
+    distinct = len({informative(d) for d in everyone})
     used = dist.get_backend()
     if backend == "nccl":
         assert used == "nccl", f"bench.py measures RCCL: the process group reports backend {used!r}"
-        if distinct != world:
-            raise SystemExit(f"bench.py: {world} ranks but only {distinct} distinct GPUs ({[key(d) for d in everyone]}): one process per GPU")
+        if distinct != world and evidence in ("pci_bus_id", "uuid"):
+            raise SystemExit(f"bench.py: {world} ranks but only {distinct} distinct GPUs by {evidence} "
+                             f"({[informative(d)[1] for d in everyone]}): one process per GPU")
     try:
         ver = ".".join(str(v) for v in torch.cuda.nccl.version())
     except Exception:
         ver = None
     buckets = model.gradient_buckets()
     return {"world": world, "effective_world_for_averaging": net.sync.world, "backend": used, "distinct_devices": distinct,
+            "distinctness_evidence": evidence,
             "devices": [{k: d[k] for k in ("rank", "device_index", "uuid", "pci_bus_id", "name")} for d in everyone],
             "nccl_version": ver, "allreduce_bytes_per_step": int(sum(4 * (hi - lo) for lo, hi in buckets)),
             "buckets": [{"floats": int(hi - lo), "bytes": int(4 * (hi - lo))} for lo, hi in buckets],
