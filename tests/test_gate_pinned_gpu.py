@@ -23,7 +23,8 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("tag,B,HW,C,seed,loss", [("b8_96_c30", 8, 96, 30, 11, "entropic"), ("b16_64_c116", 16, 64, 116, 5, "entropic"),
-                                                  ("b6_75x91_c152_garbage", 6, (75, 91), 152, 21, "garbage")])
+                                                  ("b6_75x91_c152_garbage", 6, (75, 91), 152, 21, "garbage"),
+                                                  ("b4_224_c30", 4, 224, 30, 31, "entropic")])   # the benchmark's geometry: every layer's real H x W
 def test_all_gradients_vs_fp64_oracle_under_the_hip_gates(cuda, tag, B, HW, C, seed, loss):
     from openset_imagenet import ResNet50, EntropicOpensetLoss, GarbageLoss
     from oracle import resnet50_oracle as R, losses_oracle as L
