@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*stem_direct*/ 1};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1};
 
 namespace {
 int* tuning_slot(const char* name) {
@@ -20,6 +20,8 @@ int* tuning_slot(const char* name) {
     if (!strcmp(name, "wgrad3_blocks")) return &g_osi_tuning.wgrad3_blocks;
     if (!strcmp(name, "tail_split")) return &g_osi_tuning.tail_split;
     if (!strcmp(name, "tail_cus")) return &g_osi_tuning.tail_cus;
+    if (!strcmp(name, "tail_smax")) return &g_osi_tuning.tail_smax;
+    if (!strcmp(name, "tail_mint")) return &g_osi_tuning.tail_mint;
     if (!strcmp(name, "stem_direct")) return &g_osi_tuning.stem_direct;
     return nullptr;
 }

@@ -1775,10 +1775,11 @@ struct TailPlan { int MT1, S, ksT, tiles; };   // tiles = remainder tiles ((MT -
 // MT x NT tiles of 64x64, T K-tiles each. Splits the ragged last round when the model says it buys at least 8 % of the launch and
 // every split keeps at least 2 K tiles. Measured (tools/bench_tail.py, B = 128): 3 rounds + 16 tiles (7x7 layers) +15 %, 6 rounds +
 // 32 tiles (14x14, 256 channels) +7.5 %, 12 rounds + 64 tiles (a 5.8 % model gain) -1.5 ... -3.6 %: the fix-up pass and its launch
-// boundary cost what the balance returns, so those launches stay single-pass.
+// boundary cost what the balance returns, so those launches stay single-pass. Few, long splits beat many short ones on the 1x1 layers
+// (at most 8 splits of at least 16 K tiles: 2048->512 @7x7 108 -> 119 TFLOP/s, 1024->256 @14x14 119 -> 126 against 32 / 2).
 static TailPlan plan_tail_split(long MT, int NT, int T) {
     TailPlan t{(int)MT, 1, T, 0};
-    if (!g_osi_tuning.tail_split || T < 4) return t;
+    if (!g_osi_tuning.tail_split || T < 4 || g_osi_tuning.tail_mint < 1) return t;
     const long ncu = chip_cus(), V = MT * NT;
     const long q = V / ncu, r = V - q * ncu;
     if (r == 0 || q > 8) return t;
@@ -1786,8 +1787,8 @@ static TailPlan plan_tail_split(long MT, int NT, int T) {
     long MT1 = q * ncu / NT;                       // full rounds, in whole row tiles
     long rem = (MT - MT1) * NT;
     long S = ncu / rem;
-    if (S > T / 2) S = T / 2;
-    if (S > 32) S = 32;
+    if (S > T / g_osi_tuning.tail_mint) S = T / g_osi_tuning.tail_mint;
+    if (S > g_osi_tuning.tail_smax) S = g_osi_tuning.tail_smax;
     if (S <= 1) return t;
     const int ksT = (int)((T + S - 1) / S);
     S = (T + ksT - 1) / ksT;

@@ -33,6 +33,8 @@ struct OsiTuning {
     int wgrad_group;    // weight-gradient block -> XCD mapping: 0 plain 2-D grid, 1 the R*S taps of a cell share an XCD, 2 whole K splits do
     int tail_split;     // 1 = forward / input-gradient launches split the tiles of their ragged last round along K (plan_tail_split)
     int tail_cus;       // CU count the tail plan balances for; 0 = ask the device (256 on MI355X)
+    int tail_smax;      // most K splits a remainder tile is cut into
+    int tail_mint;      // fewest K tiles (of 32) a split keeps
     int stem_direct;    // 1 = the stem convolution runs its direct form (k_stem_fwd_direct) where the geometry allows, 0 = implicit GEMM
 };
 extern OsiTuning g_osi_tuning;

@@ -54,6 +54,7 @@ def test_forward_tail_split_vs_fp64_and_unsplit(cuda, Cin, Cout, k, stride, H, B
     d = N.ConvDesc.make(B, H, H, Cin, Cout, k, stride, pad)
     M = B * d.Ho * d.Wo
     N.check(L.osi_set_tuning(b"tail_cus", cus))
+    N.check(L.osi_set_tuning(b"tail_mint", 2)); N.check(L.osi_set_tuning(b"tail_smax", 32))    # small shapes: short splits allowed
     try:
         nb = L.osi_conv_fwd_bnstats_workspace(ctypes.byref(d))
         N.check(L.osi_set_tuning(b"tail_split", 0))
@@ -68,6 +69,7 @@ def test_forward_tail_split_vs_fp64_and_unsplit(cuda, Cin, Cout, k, stride, H, B
     finally:
         N.check(L.osi_set_tuning(b"tail_cus", 0))
         N.check(L.osi_set_tuning(b"tail_split", 1))
+        N.check(L.osi_set_tuning(b"tail_mint", 16)); N.check(L.osi_set_tuning(b"tail_smax", 8))
     K = Cin * k * k
     tol = (2e-6 + 6e-8 * K ** 0.5) * float(ref.abs().max()) + 1e-6
     assert float((y1.double() - ref).abs().max()) <= tol and float((y0.double() - ref).abs().max()) <= tol
@@ -167,6 +169,7 @@ def test_input_gradient_tail_split_vs_fp64_and_unsplit(cuda, Cin, Cout, k, H, B,
         return gbuf, parts[:3 * P.value * Cin].clone().view(3, P.value, Cin), P.value
 
     N.check(L.osi_set_tuning(b"tail_cus", cus))
+    N.check(L.osi_set_tuning(b"tail_mint", 2)); N.check(L.osi_set_tuning(b"tail_smax", 32))
     try:
         pb = L.osi_conv_dgrad_fused_workspace(ctypes.byref(d))
         N.check(L.osi_set_tuning(b"tail_split", 0))
@@ -179,6 +182,7 @@ def test_input_gradient_tail_split_vs_fp64_and_unsplit(cuda, Cin, Cout, k, H, B,
     finally:
         N.check(L.osi_set_tuning(b"tail_cus", 0))
         N.check(L.osi_set_tuning(b"tail_split", 1))
+        N.check(L.osi_set_tuning(b"tail_mint", 16)); N.check(L.osi_set_tuning(b"tail_smax", 8))
     ref = torch.nn.grad.conv2d_input((B, Cin, H, H), T.oihw(w.double()), T.nchw(dy.double()), 1, pad).permute(0, 2, 3, 1)
     if add:
         ref = ref + addend.double()
