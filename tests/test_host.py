@@ -170,7 +170,7 @@ def test_tuning_knobs_are_explicit():
     finally:
         lib.osi_resnet50_destroy(h)
     src = "".join(open(os.path.join(os.path.dirname(__file__), "..", "openset-imagenet_amd", "csrc", f)).read()
-                  for f in ("conv_igemm.hip", "bn.hip", "resnet50_exec.hip", "pool_layout.hip", "loss.hip", "optim.hip", "linear.hip"))
+                  for f in ("conv_igemm.hip", "stem_direct.hip", "bn.hip", "resnet50_exec.hip", "pool_layout.hip", "loss.hip", "optim.hip", "linear.hip"))
     assert "getenv" not in src
 
 
