@@ -145,6 +145,64 @@ __global__ __launch_bounds__(NT) void k_bn_stats_final_rows(const float* __restr
         bn_finish(c, mean, m2, M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
     }
 }
+// Single-launch finalisation for mid-sized P (round 3): 16 channels x 64 partial lanes per workgroup, ONE pass over the partials with
+// four independent loads in flight per lane. Shifted sums with the first tile's mean as pivot (within a few sigma / sqrt(rows) of the
+// batch mean, so S2 - S1^2 / M does not cancel):  S1 = sum n_b (mean_b - pv),  S2 = sum [ M2_b + n_b (mean_b - pv)^2 ],
+// mean = pv + S1 / M,  M2 = S2 - S1^2 / M. Fixed summation order (lane stride, then lanes in order): bitwise reproducible.
+constexpr int WPL = 64;   // partial lanes of the wide finalisers
+__device__ __forceinline__ float wide_reduce(float (*red)[16], float v, int pl, int cl) {
+    // 64 lane values of channel cl -> their sum in lane order, returned to pl == 0
+    red[pl][cl] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (pl < 4) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[pl * 16 + k][cl];
+    }
+    __syncthreads();
+    if (pl < 4) red[pl][cl] = t;
+    __syncthreads();
+    if (pl == 0) t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    __syncthreads();
+    return t;
+}
+__global__ __launch_bounds__(16 * WPL) void k_bn_stats_final_wide(const float* __restrict__ pmean, const float* __restrict__ pm2, int P,
+                                                                 int rows_per_blk, int M, int C, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, float momentum,
+                                                                 float* running_mean, float* running_var, float* __restrict__ mean_out,
+                                                                 float* __restrict__ invstd_out, float* __restrict__ scale_out,
+                                                                 float* __restrict__ shift_out) {
+    __shared__ float red[WPL][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = min(blockIdx.x * 16 + cl, C - 1);   // lanes past C repeat the last channel and do not write
+    const bool ok = blockIdx.x * 16 + cl < C;
+    const int last = P - 1;
+    const float nfull = (float)rows_per_blk, nlast = (float)(M - last * rows_per_blk);
+    const float pv = pmean[c];
+    const float* pa = pmean + c;
+    const float* pb = pm2 + c;
+    float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
+    int b = pl;
+    for (; b + 3 * WPL < P; b += 4 * WPL) {
+        const float m0 = pa[(size_t)b * C], m1 = pa[(size_t)(b + WPL) * C], m2_ = pa[(size_t)(b + 2 * WPL) * C], m3 = pa[(size_t)(b + 3 * WPL) * C];
+        const float q0 = pb[(size_t)b * C], q1 = pb[(size_t)(b + WPL) * C], q2 = pb[(size_t)(b + 2 * WPL) * C], q3 = pb[(size_t)(b + 3 * WPL) * C];
+        const float d0 = m0 - pv, d1 = m1 - pv, d2 = m2_ - pv, d3 = m3 - pv;
+        const float n3 = b + 3 * WPL == last ? nlast : nfull;     // only the last of the four can be the ragged tile
+        s1a += nfull * d0; s1b += nfull * d1; s1a += nfull * d2; s1b += n3 * d3;
+        s2a += q0 + nfull * d0 * d0; s2b += q1 + nfull * d1 * d1; s2a += q2 + nfull * d2 * d2; s2b += q3 + n3 * d3 * d3;
+    }
+    for (; b < P; b += WPL) {
+        const float d = pa[(size_t)b * C] - pv, n = b == last ? nlast : nfull;
+        s1a += n * d; s2a += pb[(size_t)b * C] + n * d * d;
+    }
+    const float S1 = wide_reduce(red, s1a + s1b, pl, cl);
+    const float S2 = wide_reduce(red, s2a + s2b, pl, cl);
+    if (pl == 0 && ok) {
+        const float mean = pv + S1 / (float)M;
+        const float m2 = fmaxf(S2 - S1 * S1 / (float)M, 0.f);
+        bn_finish(c, mean, m2, M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
+    }
+}
 // Level 1 of the two-level finalisation: group s (blockIdx.y) reduces row tiles [s*Pc, (s+1)*Pc) of 16 channels to one
 // (mean, M2) pair per channel, division-free, written channel-major [C][S] for k_bn_stats_final.
 __global__ __launch_bounds__(NT) void k_bn_stats_group(const float* __restrict__ pmean, const float* __restrict__ pm2, int P, int Pc,
@@ -402,6 +460,33 @@ __global__ __launch_bounds__(NT) void k_colsum2_group(const float* __restrict__ 
     }
 }
 
+// Single-launch form of k_colsum2_group + k_bn_bwd_final for mid-sized P: 16 channels x 64 row lanes, four loads in flight per lane.
+__global__ __launch_bounds__(16 * WPL) void k_bn_bwd_final_wide(const float* __restrict__ a, const float* __restrict__ b, int P, int M, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ c1, float* __restrict__ c2) {
+    __shared__ float red[WPL][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = min(blockIdx.x * 16 + cl, C - 1);
+    const bool ok = blockIdx.x * 16 + cl < C;
+    const float* pa = a + c;
+    const float* pb = b + c;
+    float xa0 = 0.f, xa1 = 0.f, xb0 = 0.f, xb1 = 0.f;
+    int r = pl;
+    for (; r + 3 * WPL < P; r += 4 * WPL) {
+        const float a0 = pa[(size_t)r * C], a1 = pa[(size_t)(r + WPL) * C], a2 = pa[(size_t)(r + 2 * WPL) * C], a3 = pa[(size_t)(r + 3 * WPL) * C];
+        const float b0 = pb[(size_t)r * C], b1 = pb[(size_t)(r + WPL) * C], b2 = pb[(size_t)(r + 2 * WPL) * C], b3 = pb[(size_t)(r + 3 * WPL) * C];
+        xa0 += a0; xa1 += a1; xa0 += a2; xa1 += a3;
+        xb0 += b0; xb1 += b1; xb0 += b2; xb1 += b3;
+    }
+    for (; r < P; r += WPL) { xa0 += pa[(size_t)r * C]; xb0 += pb[(size_t)r * C]; }
+    const float sa = wide_reduce(red, xa0 + xa1, pl, cl);
+    const float sb = wide_reduce(red, xb0 + xb1, pl, cl);
+    if (pl == 0 && ok) {
+        dbeta[c] = sa; dgamma[c] = sb;
+        c1[c] = sa / (float)M; c2[c] = sb / (float)M;
+    }
+}
+
 template <int MODE, bool EMITG>
 __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const f32x4* dA /* may alias dy */, const void* __restrict__ msk,
                                                     const f32x4* __restrict__ y, const f32x4* __restrict__ mean,
@@ -482,6 +567,12 @@ int osi_bn_finalize_stats(float* pstats, size_t pstats_bytes, int P, int rows_pe
     const float* pm2 = pstats + (size_t)P * C;
     if (P <= g_osi_tuning.bn_single_p) {   // one launch merges up to this many row-tile partials per channel (measured knob)
         hipLaunchKernelGGL(k_bn_stats_final_rows, dim3(osi_cdiv(C, 16)), dim3(NT), 0, st, pmean, pm2, P, rows_per_block, M, C, gamma,
+                           beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+        OSI_LAUNCH_CHECK();
+        return OSI_OK;
+    }
+    if (P <= g_osi_tuning.bn_wide_p) {     // mid-sized P: still one launch, 64 partial lanes per channel
+        hipLaunchKernelGGL(k_bn_stats_final_wide, dim3(osi_cdiv(C, 16)), dim3(16 * WPL), 0, st, pmean, pm2, P, rows_per_block, M, C, gamma,
                            beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
         OSI_LAUNCH_CHECK();
         return OSI_OK;
@@ -593,6 +684,22 @@ static int bn_backward_impl(const float* dout, const void* msk, int mode, const 
     return OSI_OK;
 }
 
+// (psum_g, psum_gx)[P][C] from a dgrad epilogue -> dgamma, dbeta and the two apply coefficients: one launch for P <= bn_wide_p, else two
+static int bwd_reduce_partials(const float* psum_g, const float* psum_gx, int P, int M, int C, float* gb, float* gg, int S, int Pc,
+                               float* dgamma, float* dbeta, float* c1, float* c2, hipStream_t st) {
+    if (P <= g_osi_tuning.bn_wide_p) {
+        hipLaunchKernelGGL(k_bn_bwd_final_wide, dim3(osi_cdiv(C, 16)), dim3(16 * WPL), 0, st, psum_g, psum_gx, P, M, C, dgamma, dbeta, c1, c2);
+        OSI_LAUNCH_CHECK();
+        return OSI_OK;
+    }
+    hipLaunchKernelGGL(k_colsum2_group, dim3(osi_cdiv(C, 16), S), dim3(NT), 0, st, psum_g, psum_gx, P, Pc, C, S, gb, gg);
+    OSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, (const float*)gb, (const float*)gg, S, M, C, dgamma,
+                       dbeta, c1, c2);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
 int osi_bn_backward_fused(const float* g, const float* y, const float* mean, const float* invstd, const float* gamma,
                           const float* psum_g, const float* psum_gx, int P, float* dy, float* dgamma, float* dbeta, int M, int C,
                           void* ws, size_t ws_bytes, osi_stream_t stream) {
@@ -608,11 +715,7 @@ int osi_bn_backward_fused(const float* g, const float* y, const float* mean, con
     float* gg = gb + (size_t)S * C;       // [C][S] group sums of g*xhat
     float* c1 = gg + (size_t)S * C;
     float* c2 = c1 + C;
-    hipLaunchKernelGGL(k_colsum2_group, dim3(osi_cdiv(C, 16), S), dim3(NT), 0, st, psum_g, psum_gx, P, Pc, C, S, gb, gg);
-    OSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, (const float*)gb, (const float*)gg, S, M, C, dgamma,
-                       dbeta, c1, c2);
-    OSI_LAUNCH_CHECK();
+    if (int e = bwd_reduce_partials(psum_g, psum_gx, P, M, C, gb, gg, S, Pc, dgamma, dbeta, c1, c2, st)) return e;
     const size_t n4 = (size_t)M * C / 4;
     hipLaunchKernelGGL((k_bn_bwd_apply<0, false>), dim3(stream_grid(n4)), dim3(NT), 0, st, (const f32x4*)g, (const void*)nullptr,
                        (const f32x4*)y, (const f32x4*)mean, (const f32x4*)invstd, (const f32x4*)gamma, (const f32x4*)c1,
@@ -634,11 +737,7 @@ int osi_bn_backward_reduce(const float* psum_g, const float* psum_gx, int P, flo
     float* gg = gb + (size_t)S * C;
     float* c1 = gg + (size_t)S * C;
     float* c2 = c1 + C;
-    hipLaunchKernelGGL(k_colsum2_group, dim3(osi_cdiv(C, 16), S), dim3(NT), 0, st, psum_g, psum_gx, P, Pc, C, S, gb, gg);
-    OSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(osi_cdiv(C, NT / 64)), dim3(NT), 0, st, (const float*)gb, (const float*)gg, S, M, C, dgamma,
-                       dbeta, c1, c2);
-    OSI_LAUNCH_CHECK();
+    if (int e = bwd_reduce_partials(psum_g, psum_gx, P, M, C, gb, gg, S, Pc, dgamma, dbeta, c1, c2, st)) return e;
     return OSI_OK;
 }
 

@@ -389,7 +389,8 @@ def test_batchnorm_relu_bitmask_forms(cuda, B, C, H, res):
 
 
 @pytest.mark.parametrize("Cin,Cout,k,stride,H,B", [(64, 64, 1, 1, 14, 3), (128, 128, 3, 2, 9, 3), (256, 512, 1, 1, 7, 5), (64, 256, 3, 1, 12, 2),
-                                                    (64, 64, 1, 1, 56, 3)])   # the last one has 147 row tiles -> two-level finalisation
+                                                    (64, 64, 1, 1, 56, 3),    # 147 row tiles: past bn_single_p
+                                                    (64, 64, 1, 1, 51, 5)])   # 204 row tiles, the last one ragged: the wide form's unrolled loop
 def test_conv_epilogue_batchnorm_statistics(cuda, Cin, Cout, k, stride, H, B):
     """BN statistics emitted by the conv-forward epilogue + osi_bn_finalize_stats == statistics of the conv output (fp64),
     for every tile shape (ragged last row tile included), and the conv output itself is unchanged."""
@@ -424,15 +425,24 @@ def test_conv_epilogue_batchnorm_statistics(cuda, Cin, Cout, k, stride, H, B):
             N.check(L.osi_conv_fwd_bnstats(ctypes.byref(d), N.ptr(xg), N.ptr(wg), N.ptr(y), tile, N.ptr(ps), nb, ctypes.byref(P), ctypes.byref(rows), T.S()))
         else:
             assert torch.equal(y, T.conv_fwd(xg, wg, k, stride, pad, tile))
-        mean, invstd, scale, shift = (torch.empty(Cout, device=cuda) for _ in range(4))
-        rm, rv = torch.zeros(Cout, device=cuda), torch.ones(Cout, device=cuda)
-        N.check(L.osi_bn_finalize_stats(N.ptr(ps), nb, P.value, rows.value, M, Cout, N.ptr(ga), N.ptr(be), 1e-5, 0.1, N.ptr(rm), N.ptr(rv),
-                                        N.ptr(mean), N.ptr(invstd), N.ptr(scale), N.ptr(shift), T.S()))
-        assert float((mean.cpu().double() - mean64).abs().max()) <= 2e-6 * float(y64.abs().max()), f"tile {tile} mean"
-        inv64 = 1 / torch.sqrt(var64 + 1e-5)
-        assert float(((invstd.cpu().double() - inv64) / inv64).abs().max()) <= 2e-5, f"tile {tile} invstd"
-        assert torch.allclose(rv.cpu().double(), 0.9 + 0.1 * var64 * M / (M - 1), rtol=2e-5)
-        assert torch.allclose(scale, ga * invstd) and torch.allclose(shift, be - mean * scale, atol=1e-6)
+        # every finalisation form the partial count admits: one 256-thread launch (P <= bn_single_p), one 1024-thread launch
+        # (P <= bn_wide_p), two levels (above); the knobs force each in turn
+        for single_p, wide_p in ((128, 2048), (1, 2048), (1, 0)):
+            N.check(L.osi_set_tuning(b"bn_single_p", single_p)); N.check(L.osi_set_tuning(b"bn_wide_p", wide_p))
+            try:
+                mean, invstd, scale, shift = (torch.empty(Cout, device=cuda) for _ in range(4))
+                rm, rv = torch.zeros(Cout, device=cuda), torch.ones(Cout, device=cuda)
+                N.check(L.osi_bn_finalize_stats(N.ptr(ps), nb, P.value, rows.value, M, Cout, N.ptr(ga), N.ptr(be), 1e-5, 0.1, N.ptr(rm),
+                                                N.ptr(rv), N.ptr(mean), N.ptr(invstd), N.ptr(scale), N.ptr(shift), T.S()))
+                torch.cuda.synchronize()
+            finally:
+                N.check(L.osi_set_tuning(b"bn_single_p", 128)); N.check(L.osi_set_tuning(b"bn_wide_p", 2048))
+            form = f"tile {tile} single_p {single_p} wide_p {wide_p}"
+            assert float((mean.cpu().double() - mean64).abs().max()) <= 2e-6 * float(y64.abs().max()), f"{form} mean"
+            inv64 = 1 / torch.sqrt(var64 + 1e-5)
+            assert float(((invstd.cpu().double() - inv64) / inv64).abs().max()) <= 2e-5, f"{form} invstd"
+            assert torch.allclose(rv.cpu().double(), 0.9 + 0.1 * var64 * M / (M - 1), rtol=2e-5), form
+            assert torch.allclose(scale, ga * invstd) and torch.allclose(shift, be - mean * scale, atol=1e-6), form
 
 
 class _Fusion(ctypes.Structure):
@@ -501,10 +511,17 @@ def test_dgrad_fused_epilogue_vs_unfused(cuda, Cin, Cout, k, stride, H, B, two):
         dyo, dg, db = torch.empty(M, Cin, device=cuda), torch.empty(Cin, device=cuda), torch.empty(Cin, device=cuda)
         psum_g = parts.data_ptr()
         psum_gx = parts.data_ptr() + 4 * (1 + j) * P.value * Cin
-        N.check(L.osi_bn_backward_fused(N.ptr(gbuf), N.ptr(yv), N.ptr(st[0]), N.ptr(st[1]), N.ptr(gv), psum_g, psum_gx, P.value, N.ptr(dyo),
-                                        N.ptr(dg), N.ptr(db), M, Cin, N.ptr(ws), wsb, T.S()))
-        rdy, _, rdg, rdb = ref[j]
-        scale = float(rdy.abs().max()) + 1e-30
-        assert float((dyo - rdy).abs().max()) <= 2e-5 * scale, f"dy consumer {j}"
-        assert float((dg - rdg).abs().max()) <= 2e-5 * (float(rdg.abs().max()) + 1e-30), f"dgamma consumer {j}"
-        assert float((db - rdb).abs().max()) <= 2e-5 * (float(rdb.abs().max()) + 1e-30), f"dbeta consumer {j}"
+        for wide_p in (2048, 0):        # the partial sums merged by one 1024-thread launch, and by the two-level pair
+            N.check(L.osi_set_tuning(b"bn_wide_p", wide_p))
+            try:
+                dyo.fill_(float("nan")); dg.fill_(float("nan")); db.fill_(float("nan"))
+                N.check(L.osi_bn_backward_fused(N.ptr(gbuf), N.ptr(yv), N.ptr(st[0]), N.ptr(st[1]), N.ptr(gv), psum_g, psum_gx, P.value,
+                                                N.ptr(dyo), N.ptr(dg), N.ptr(db), M, Cin, N.ptr(ws), wsb, T.S()))
+                torch.cuda.synchronize()
+            finally:
+                N.check(L.osi_set_tuning(b"bn_wide_p", 2048))
+            rdy, _, rdg, rdb = ref[j]
+            scale = float(rdy.abs().max()) + 1e-30
+            assert float((dyo - rdy).abs().max()) <= 2e-5 * scale, f"dy consumer {j} wide_p {wide_p}"
+            assert float((dg - rdg).abs().max()) <= 2e-5 * (float(rdg.abs().max()) + 1e-30), f"dgamma consumer {j} wide_p {wide_p}"
+            assert float((db - rdb).abs().max()) <= 2e-5 * (float(rdb.abs().max()) + 1e-30), f"dbeta consumer {j} wide_p {wide_p}"
