@@ -1211,16 +1211,29 @@ __global__ __launch_bounds__(256) void k_conv_fwd_tail_fixup(ConvP p) {
     const int tile = blockIdx.x;
     const int mt = p.MT1 + tile / p.NT, nt = tile - (tile / p.NT) * p.NT;
     const int m0 = mt * 64, n0 = nt * 64;
-    const float* src = p.ks_slab + (size_t)tile * p.ks_S * 4096;
     const int tid = threadIdx.x, c4 = tid & 15, rg = tid >> 4;
+    // the tile's S slabs behind one buffer descriptor: a split index past S reads as zero through the range check, so the loads of
+    // four splits x four rows go out together (the split ORDER of every sum stays 0, 1, 2, ...: bitwise reproducible)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.ks_slab + (size_t)tile * p.ks_S * 4096, p.ks_S * 16384);
+    const uint32_t off = (uint32_t)(rg * 64 + c4 * 4) * 4u;
     f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = bld4(rs, off + (uint32_t)k * 4096u, 0);
+    for (int s0 = 1; s0 < p.ks_S; s0 += 4) {
+        f32x4 t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[j][k] = bld4(rs, off + (uint32_t)k * 4096u + (uint32_t)(s0 + j) * 16384u, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += t[j][k];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int rl = rg + 16 * k;
-        f32x4 a = ld4(src + rl * 64 + c4 * 4);
-        for (int sp = 1; sp < p.ks_S; ++sp) a += ld4(src + (size_t)sp * 4096 + rl * 64 + c4 * 4);
-        v[k] = a;
-        if (m0 + rl < p.M) *reinterpret_cast<f32x4*>(p.y + (size_t)(m0 + rl) * p.Cout + n0 + c4 * 4) = a;
+        if (m0 + rl < p.M) *reinterpret_cast<f32x4*>(p.y + (size_t)(m0 + rl) * p.Cout + n0 + c4 * 4) = v[k];
     }
     if (!p.pmean) return;
     const float cnt = (float)min(64, p.M - m0);
@@ -1260,11 +1273,19 @@ __global__ __launch_bounds__(256) void k_conv_dgrad_tail_fixup(ConvP p) {
     __shared__ float red[4 * 64 * 3];
     const int tile = blockIdx.x;
     const int mt = p.MT1 + tile / p.NT, nt = tile - (tile / p.NT) * p.NT;
-    const float* src = p.ks_slab + (size_t)tile * p.ks_S * 4096;
     const int nsp = p.ks_S;
+    // one descriptor over the tile's slabs: splits past nsp read as zero, so eight loads go out together; sums stay in split order
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.ks_slab + (size_t)tile * nsp * 4096, nsp * 16384);
     dgrad_epilogue64<FUSED, false>(p, red, 0, mt, mt * 64, nt * 64, p.B * p.H * p.W, 1, 0, 0, p.cHW[0], p.cW[0], [&](int rl, int c4) {
-        f32x4 a = ld4(src + rl * 64 + c4 * 4);
-        for (int sp = 1; sp < nsp; ++sp) a += ld4(src + (size_t)sp * 4096 + rl * 64 + c4 * 4);
+        const uint32_t off = (uint32_t)(rl * 64 + c4 * 4) * 4u;
+        f32x4 a = bld4(rs, off, 0);
+        for (int s0 = 1; s0 < nsp; s0 += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = bld4(rs, off + (uint32_t)(s0 + j) * 16384u, 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += t[j];
+        }
         return a;
     });
 }
@@ -1357,8 +1378,8 @@ static TailPlan plan_tail_split(long MT, int NT, int T) {
     if (!g_osi_tuning.tail_split || T < 4 || g_osi_tuning.tail_mint < 1) return t;
     const long ncu = chip_cus(), V = MT * NT;
     const long q = V / ncu, r = V - q * ncu;
-    if (r == 0 || q > 8) return t;
-    if ((double)(ncu - r) / (double)ncu / (double)(q + 1) < 0.08) return t;
+    if (r == 0 || q > g_osi_tuning.tail_qmax) return t;
+    if ((double)(ncu - r) / (double)ncu / (double)(q + 1) * 100.0 < (double)g_osi_tuning.tail_gain) return t;
     long MT1 = q * ncu / NT;                       // full rounds, in whole row tiles
     long rem = (MT - MT1) * NT;
     long S = ncu / rem;
