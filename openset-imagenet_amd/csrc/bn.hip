@@ -208,40 +208,39 @@ __global__ __launch_bounds__(16 * WPL) void k_bn_stats_final_wide(const float* _
 __global__ __launch_bounds__(NT) void k_bn_stats_group(const float* __restrict__ pmean, const float* __restrict__ pm2, int P, int Pc,
                                                       int rows_per_blk, int M, int C, int S, float* __restrict__ gmean,
                                                       float* __restrict__ gm2) {
-    __shared__ float red[16][16];
-    __shared__ float smean[16];
+    // one pass of shifted sums (pivot = the group's first tile mean), four row tiles in flight per lane; see k_bn_stats_final_wide
+    __shared__ float red[2][16][16];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl, s = blockIdx.y;
-    const bool ok = c < C;
+    const int c = min(blockIdx.x * 16 + cl, C - 1), s = blockIdx.y;
+    const bool ok = blockIdx.x * 16 + cl < C;
     const int b0 = s * Pc, b1 = min(P, b0 + Pc), last = P - 1;
     const float nfull = (float)rows_per_blk, nlast = (float)(M - last * rows_per_blk);
     const float ng = (float)(min(M, b1 * rows_per_blk) - b0 * rows_per_blk);
-    float a = 0.f;
-    if (ok)
-        for (int b = b0 + pl; b < b1; b += 16) a += (b == last ? nlast : nfull) * pmean[(size_t)b * C + c];
-    red[pl][cl] = a;
-    __syncthreads();
-    if (pl == 0) {
-        float t = 0.f;
-        for (int k = 0; k < 16; ++k) t += red[k][cl];
-        smean[cl] = t / ng;
+    const float* pa = pmean + c;
+    const float* pb = pm2 + c;
+    const float pv = pa[(size_t)b0 * C];
+    float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
+    int b = b0 + pl;
+    for (; b + 48 < b1; b += 64) {
+        const float m0 = pa[(size_t)b * C], m1 = pa[(size_t)(b + 16) * C], m2_ = pa[(size_t)(b + 32) * C], m3 = pa[(size_t)(b + 48) * C];
+        const float q0 = pb[(size_t)b * C], q1 = pb[(size_t)(b + 16) * C], q2 = pb[(size_t)(b + 32) * C], q3 = pb[(size_t)(b + 48) * C];
+        const float d0 = m0 - pv, d1 = m1 - pv, d2 = m2_ - pv, d3 = m3 - pv;
+        const float n3 = b + 48 == last ? nlast : nfull;
+        s1a += nfull * d0; s1b += nfull * d1; s1a += nfull * d2; s1b += n3 * d3;
+        s2a += q0 + nfull * d0 * d0; s2b += q1 + nfull * d1 * d1; s2a += q2 + nfull * d2 * d2; s2b += q3 + n3 * d3 * d3;
     }
-    __syncthreads();
-    const float mean = smean[cl];
-    a = 0.f;
-    if (ok)
-        for (int b = b0 + pl; b < b1; b += 16) {
-            const float d = pmean[(size_t)b * C + c] - mean;
-            a += pm2[(size_t)b * C + c] + (b == last ? nlast : nfull) * d * d;
-        }
-    __syncthreads();
-    red[pl][cl] = a;
+    for (; b < b1; b += 16) {
+        const float d = pa[(size_t)b * C] - pv, n = b == last ? nlast : nfull;
+        s1a += n * d; s2a += pb[(size_t)b * C] + n * d * d;
+    }
+    red[0][pl][cl] = s1a + s1b; red[1][pl][cl] = s2a + s2b;
     __syncthreads();
     if (pl == 0 && ok) {
-        float m2 = 0.f;
-        for (int k = 0; k < 16; ++k) m2 += red[k][cl];
-        gmean[(size_t)c * S + s] = mean;
-        gm2[(size_t)c * S + s] = m2;
+        float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { S1 += red[0][k][cl]; S2 += red[1][k][cl]; }
+        gmean[(size_t)c * S + s] = pv + S1 / ng;
+        gm2[(size_t)c * S + s] = fmaxf(S2 - S1 * S1 / ng, 0.f);
     }
 }
 __global__ __launch_bounds__(NT) void k_bn_stats_final(const float* __restrict__ pmean, const float* __restrict__ pm2, int P,
@@ -447,14 +446,24 @@ __global__ __launch_bounds__(NT) void k_colsum2_group(const float* __restrict__ 
                                                      int S, float* __restrict__ ga, float* __restrict__ gb) {
     __shared__ float ra[16][16], rb[16][16];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl, s = blockIdx.y;
+    const int c = min(blockIdx.x * 16 + cl, C - 1), s = blockIdx.y;
+    const bool ok = blockIdx.x * 16 + cl < C;
     const int b0 = s * Pc, b1 = min(P, b0 + Pc);
-    float xa = 0.f, xb = 0.f;
-    if (c < C)
-        for (int r = b0 + pl; r < b1; r += 16) { xa += a[(size_t)r * C + c]; xb += b[(size_t)r * C + c]; }
+    const float* pa = a + c;
+    const float* pb = b + c;
+    float xa0 = 0.f, xa1 = 0.f, xb0 = 0.f, xb1 = 0.f;
+    int r = b0 + pl;
+    for (; r + 48 < b1; r += 64) {     // four rows in flight per lane
+        const float a0 = pa[(size_t)r * C], a1 = pa[(size_t)(r + 16) * C], a2 = pa[(size_t)(r + 32) * C], a3 = pa[(size_t)(r + 48) * C];
+        const float v0 = pb[(size_t)r * C], v1 = pb[(size_t)(r + 16) * C], v2 = pb[(size_t)(r + 32) * C], v3 = pb[(size_t)(r + 48) * C];
+        xa0 += a0; xa1 += a1; xa0 += a2; xa1 += a3;
+        xb0 += v0; xb1 += v1; xb0 += v2; xb1 += v3;
+    }
+    for (; r < b1; r += 16) { xa0 += pa[(size_t)r * C]; xb0 += pb[(size_t)r * C]; }
+    float xa = xa0 + xa1, xb = xb0 + xb1;
     ra[pl][cl] = xa; rb[pl][cl] = xb;
     __syncthreads();
-    if (pl == 0 && c < C) {
+    if (pl == 0 && ok) {
         for (int k = 1; k < 16; ++k) { xa += ra[k][cl]; xb += rb[k][cl]; }
         ga[(size_t)c * S + s] = xa; gb[(size_t)c * S + s] = xb;
     }

@@ -37,7 +37,15 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dy,
     const int b = blockIdx.y;
     if (k >= K) return;
     float acc = 0.f;
-    for (int o = 0; o < O; ++o) acc += dy[(size_t)b * O + o] * w[(size_t)o * K + k];
+    int o = 0;
+    for (; o + 8 <= O; o += 8) {    // eight loads in flight; the sum keeps the order o = 0, 1, 2, ...
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = w[(size_t)(o + j) * K + k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += dy[(size_t)b * O + o + j] * wv[j];
+    }
+    for (; o < O; ++o) acc += dy[(size_t)b * O + o] * w[(size_t)o * K + k];
     float* d = dx + (size_t)b * K + k;
     *d = accumulate ? *d + acc : acc;
 }
@@ -48,7 +56,15 @@ __global__ __launch_bounds__(256) void k_linear_dw(const float* __restrict__ dy,
     const int o = blockIdx.y;
     if (k >= K) return;
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += dy[(size_t)b * O + o] * x[(size_t)b * K + k];
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {    // eight loads in flight; the sum keeps the order b = 0, 1, 2, ...
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = x[(size_t)(b + j) * K + k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += dy[(size_t)(b + j) * O + o] * xv[j];
+    }
+    for (; b < B; ++b) acc += dy[(size_t)b * O + o] * x[(size_t)b * K + k];
     dw[(size_t)o * K + k] = acc;
 }
 
