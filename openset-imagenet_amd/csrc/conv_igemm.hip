@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
             a_base[i] = (int)b * p.H * p.W * p.Cin * 4;
         } else if (p.unit) {
             a_base[i] = a_ok[i] ? ((int)mm * p.Cin + kq * 4) * 4 : (int)OOB;
+            a_taps[i] = a_ok[i] ? 1u : 0u;
         } else {
             a_base[i] = (((int)b * p.H * p.W + a_h0[i] * p.W + a_w0[i]) * p.Cin + kq * 4) * 4;
             for (int rr = 0; rr < p.R; ++rr)
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     const int t0 = (!KS || ks < 0) ? 0 : ks * p.ks_T;            // this workgroup's K tiles [t0, T)
     const int T = (!KS || ks < 0) ? Tall : min(Tall, t0 + p.ks_T);
     int r = 0, s = 0, c0 = 0;  // current tap / channel offset (non-stem)
-    if (KS && !STEM && ks > 0 && !p.unit) {
+    if (KS && !STEM && ks > 0) {
         const int tap = (t0 * BK) / p.Cin;
         c0 = t0 * BK - tap * p.Cin; r = tap / p.S; s = tap - r * p.S;
     }
@@ -266,22 +267,29 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     f32x4 rr[XF == 2 ? AR : 1];   // XF = 2: the shortcut rows of the tile sitting in ra
 
     auto gload = [&](int t) {
-        if (XF) { ld_c0 = p.unit ? t * BK : c0; ld_tap = r * p.S + s; }
+        if (XF) { ld_c0 = c0; ld_tap = r * p.S + s; }
         if (XF == 2) {
 #pragma unroll
             for (int i = 0; i < AR; ++i) rr[i] = bld4(rres, (uint32_t)a_base[i], (uint32_t)(t * BK * 4));
         }
+        // The run-time form (1x1 stride-1 or generic) is chosen ONCE per tile, outside the unrolled loop: with a branch per load the
+        // compiler waited for every outstanding load before the next one (the other form's destination registers count as pending
+        // across the join), so the rows of a tile paid one memory round trip each.
+        if (STEM) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            if (STEM) {
+            for (int i = 0; i < AR; ++i) {
                 int tap = t * 8 + kq;  // Cin = 4: one tap per float4
                 int rr = tap / 7, ss = tap - rr * 7;
                 int hi = a_h0[i] + rr, wi = a_w0[i] + ss;
                 bool ok = a_ok[i] && tap < 49 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 ra[i] = bld4(rx, ok ? (uint32_t)(a_base[i] + (hi * p.W + wi) * 16) : OOB, 0);
-            } else if (p.unit) {   // 1x1 stride-1: row m of the input, K offset in the scalar operand; no VALU at all
-                ra[i] = bld4(rx, (uint32_t)a_base[i], (uint32_t)(t * BK * 4));
-            } else {
+            }
+        } else if (p.unit) {   // 1x1 stride-1: row m of the input, K offset in the scalar operand; no VALU at all
+#pragma unroll
+            for (int i = 0; i < AR; ++i) ra[i] = bld4(rx, (uint32_t)a_base[i], (uint32_t)(t * BK * 4));
+        } else {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
                 const bool ok = (a_taps[i] >> (r * p.S + s)) & 1;
                 ra[i] = bld4(rx, ok ? (uint32_t)(a_base[i] + ((r * p.W + s) * p.Cin + c0) * 4) : OOB, 0);
             }
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
             }
             // 1x1 stride-1: only rows past M are invalid and their results are never stored; otherwise padding taps must read as
             // the zero the reference pads the ACTIVATION with
-            const bool ok = p.unit ? true : (((a_taps[i] >> ld_tap) & 1) != 0);
+            const bool ok = ((a_taps[i] >> ld_tap) & 1) != 0;
             ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -544,7 +552,7 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
 // POOL: pool-mode reductions in the epilogue (osi_dgrad_fusion.pool_idx) — one launch per step, its own instantiation so that the
 // workhorse keeps its 8 waves per SIMD
 template <int WM, int WN, int NST, bool FUSED, bool KS = false, bool POOL = false>
-__global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0) {
+__global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ? 8 : 4)) : 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0) {
     static_assert(!KS || (WM == 1 && WN == 1 && NST == 1), "the K-split tail is built for the single-buffered 64x64 tile");
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32;
@@ -632,11 +640,12 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
 
     auto gload = [&]() {
         const int r = rb + st * jr, s = sb + st * js;
+        if (p.unit) {   // the form is chosen once per tile, outside the unrolled loop (see k_conv_fwd's gload)
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            if (p.unit) {
-                ra[i] = bld4(rx, (uint32_t)a_base[i], (uint32_t)(c0 * 4));
-            } else {
+            for (int i = 0; i < AR; ++i) ra[i] = bld4(rx, (uint32_t)a_base[i], (uint32_t)(c0 * 4));
+        } else {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
                 const bool ok = (a_taps[i] >> (jr * nS + js)) & 1;
                 ra[i] = bld4(rx, ok ? (uint32_t)(a_base[i] + (c0 - (jr * p.Wo + js) * p.Cout) * 4) : OOB, 0);
             }
@@ -807,7 +816,7 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2) void k_
 template <int WM, int WN, bool STEM, int NST, bool XF = false>
 // Register budget = what the split-K plan can keep resident anyway (plan_wgrad sizes a launch for two 128x128, four 128x64 or eight
 // 64x64 workgroups per CU): 3 / 4 / 7-8 waves per SIMD. Asking for more only forces spills into the K loop.
-__global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 3 : (WM * WN == 2 ? 5 : 8)) : 2) void k_conv_wgrad(ConvP p) {
+__global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 4 : (WM * WN == 2 ? 5 : 8)) : 2) void k_conv_wgrad(ConvP p) {
     static_assert(!(XF && STEM), "the stem reads the image, not an activation");
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -908,32 +917,40 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 3 : (WM * WN == 2 ?
             const int m = kb + a_row + ARP * i;
             ra[i] = bld4(rdy, m < kend ? (uint32_t)(((a_row + ARP * i) * p.Cout + n0 + a_col) * 4) : OOB, (uint32_t)kb * p.Cout * 4);
         }
+        // ONE straight-line path for both run-time forms (a branch per load, or per form, made the compiler wait for every
+        // outstanding load before the next one: the destination registers of the other form's loads count as pending across the
+        // join): 1x1 stride-1 takes the pixel offset from m itself, everything else from the rolling LDS table; the table read is
+        // issued either way (zeros / stale entries in the 1x1 stride-1 form, selected away)
+        if (!STEM) {
+            uint32_t toff[BRN];
 #pragma unroll
-        for (int i = 0; i < BRN; ++i) {
-            const int m = kb + b_row + BRP * i;
-            bool ok = m < kend;
-            if (!STEM && p.unit) {   // 1x1 stride-1: pixel m of the output is pixel m of the input
-                rbv[i] = bld4(rx, ok ? (uint32_t)(((b_row + BRP * i) * p.Cin + c0 + b_col) * 4) : OOB, (uint32_t)kb * p.Cin * 4);
-                continue;
+            for (int i = 0; i < BRN; ++i) toff[i] = tbl[(t % TW) * BK + b_row + BRP * i];
+#pragma unroll
+            for (int i = 0; i < BRN; ++i) {
+                const int m = kb + b_row + BRP * i;
+                const uint32_t uoff = m < kend ? (uint32_t)m * (uint32_t)(p.Cin * 4) : OOB;   // pixel m of the output = pixel m of the input
+                rbv[i] = bld4(rx, (p.unit ? uoff : toff[i]) + (uint32_t)((c0 + b_col) * 4), 0);   // OOB + a column offset is still past the end
             }
-            if (use_tbl) {   // OOB + a column offset is still past the end of the tensor
-                rbv[i] = bld4(rx, tbl[(t % TW) * BK + b_row + BRP * i] + (uint32_t)((c0 + b_col) * 4), 0);
-                continue;
+        } else {
+#pragma unroll
+            for (int i = 0; i < BRN; ++i) {
+                const int m = kb + b_row + BRP * i;
+                bool ok = m < kend;
+                uint32_t mm = ok ? (uint32_t)m : 0u;
+                uint32_t b = fdiv(mm, p.dHoWo);
+                uint32_t rem = mm - b * p.dHoWo.d;
+                uint32_t ho = fdiv(rem, p.dWo);
+                uint32_t wo = rem - ho * p.dWo.d;
+                int rr = r, ss = s, coff = c0 + b_col;
+                if (STEM) {
+                    int tp = ntile * (BN / 4) + (b_col >> 2);
+                    rr = tp / 7; ss = tp - rr * 7; coff = 0;
+                    ok = ok && tp < 49;
+                }
+                int hi = (int)ho * p.stride - p.pad + rr, wi = (int)wo * p.stride - p.pad + ss;
+                ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                rbv[i] = bld4(rx, ok ? (uint32_t)(((((int)b * p.H + hi) * p.W + wi) * p.Cin + coff) * 4) : OOB, 0);
             }
-            uint32_t mm = ok ? (uint32_t)m : 0u;
-            uint32_t b = fdiv(mm, p.dHoWo);
-            uint32_t rem = mm - b * p.dHoWo.d;
-            uint32_t ho = fdiv(rem, p.dWo);
-            uint32_t wo = rem - ho * p.dWo.d;
-            int rr = r, ss = s, coff = c0 + b_col;
-            if (STEM) {
-                int tp = ntile * (BN / 4) + (b_col >> 2);
-                rr = tp / 7; ss = tp - rr * 7; coff = 0;
-                ok = ok && tp < 49;
-            }
-            int hi = (int)ho * p.stride - p.pad + rr, wi = (int)wo * p.stride - p.pad + ss;
-            ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            rbv[i] = bld4(rx, ok ? (uint32_t)(((((int)b * p.H + hi) * p.W + wi) * p.Cin + coff) * 4) : OOB, 0);
         }
     };
     // XF: fused activation on the X tile sitting in rbv, in registers, right before the LDS store (see k_conv_fwd)
@@ -945,7 +962,7 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 3 : (WM * WN == 2 ?
             // A padding tap must read as zero AFTER the activation: select. Pixels past the split's end need nothing: their dY row
             // is zero (range-checked load), so whatever finite value relu(shift) leaves in the X row is multiplied away — the 1x1
             // stride-1 form has no padding and therefore no select at all.
-            const bool ok = p.unit ? true : (tbl[(ld_t % TW) * BK + row] != OOB);
+            const bool ok = (tbl[(ld_t % TW) * BK + row] != OOB) | (p.unit != 0);   // branch-free: the table read is issued either way
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(rbv[i][e], sc[e], sh[e]), 0.f);
@@ -1480,7 +1497,7 @@ static int launch_wgrad(ConvP p, int splits, hipStream_t st) {
     size_t smem = 2 * (size_t)BK * (BM + 4 + BN + 4) * sizeof(float);
     smem = smem / 2 * NST;
     p.wtbl = (!STEM && !p.unit) ? 1 : 0;
-    if (p.wtbl || XF) smem += 32 * BK * sizeof(uint32_t);   // TW * BK offsets
+    smem += 32 * BK * sizeof(uint32_t);   // TW * BK offsets (read, and ignored, by the 1x1 stride-1 form too)
     if (XF) smem += 2 * BN * sizeof(float);                 // scale | shift of the column tile's channels
     if (int e = set_smem(k_conv_wgrad<WM, WN, STEM, NST, XF>, smem)) return e;
     p.splits = splits;
