@@ -15,6 +15,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int 
 __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 bld4u(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// 16-byte store through the range check: an offset >= num_records (the OOB sentinel) is dropped
+__device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, f32x4 v, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef float f32x4acc __attribute__((ext_vector_type(4)));   // C/D of v_mfma_f32_16x16x4_f32
 __device__ __forceinline__ f32x3 bld3(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {

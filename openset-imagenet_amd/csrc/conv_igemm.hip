@@ -447,72 +447,121 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
 // partial sums of the consumer layer(s). `rd(row, c4)` returns the accumulated float4 of tile row `row`, channel quad `c4`: the
 // convolution kernel reads its LDS-transposed accumulators, the fix-up pass of a K-split tail sums the tile's slab entries. One
 // code path for both keeps their results identical in form (same gates, same reduction order inside the tile).
-template <bool FUSED, bool POOL, typename RD>
+// FUSED: 0 = addend only; 1 = every fusion the ABI allows (tests, pool mode); 2 = "in-block" (the gate recomputed from y0 and / or
+// the sums over y0; no addend, bitmask or second consumer: all four rows' loads in flight); 3 = "block input" (addend, bitmask,
+// sums over y0 and y1; no recomputed gate). 2 and 3 are what the executor issues; they exist so that each fits 64 registers.
+template <int FUSED, bool POOL, typename RD>
 __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, int cls, int mt, int m0, int n0, int Mc, int st, int ph,
                                                  int pw, const FastDiv& dHW, const FastDiv& dW, RD rd) {
     constexpr int BN = 64;
+    constexpr bool USE_ADD = FUSED != 2, USE_BITS = FUSED == 1 || FUSED == 3, USE_Y1 = FUSED == 1 || FUSED == 3;
+    constexpr bool USE_GATE = FUSED == 1 || FUSED == 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 15, rg = tid >> 4;
     const int col = n0 + c4 * 4;
-    f32x4 sg = {0, 0, 0, 0}, s0 = sg, s1 = sg, mu0 = sg, is0 = sg, mu1 = sg, is1 = sg, gsc = sg, gsh = sg;
-    if (FUSED && p.esum) {
-        mu0 = ld4(p.emean0 + col); is0 = ld4(p.einv0 + col);
-        if (p.ey1) { mu1 = ld4(p.emean1 + col); is1 = ld4(p.einv1 + col); }
+    // Straight-line code: every optional tensor sits behind a buffer descriptor with ZERO records when it is absent (the load
+    // returns zeros without touching memory), rows past the end of the tensor use the out-of-range offset for loads AND the store,
+    // and the run-time switches become selects. With a branch per optional tensor the compiler drained all outstanding loads at
+    // every join: the four rows of a lane paid three to four dependent memory round trips EACH, and an input-gradient tile with
+    // a short K loop spent longer in this epilogue than in its matrix work.
+    constexpr int FULL = (int)0x80000000u;    // every tensor here is < 2 GiB (desc_ok); OOB = 0x80000000 is past any of them
+    const bool has_sum = FUSED && p.esum != nullptr, has_gate = USE_GATE && p.escale0 != nullptr, has_bits = USE_BITS && p.ebits != nullptr;
+    const bool has_y1 = USE_Y1 && has_sum && p.ey1 != nullptr;
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.y, FULL);
+    f32x4 sg = {0, 0, 0, 0}, s0 = sg, s1 = sg, mu0 = sg, is0 = sg, gsc = sg, gsh = sg;
+    if (FUSED) {
+        const uint32_t cb = (uint32_t)col * 4u;
+        mu0 = bld4(make_rsrc(p.emean0, has_sum ? FULL : 0), cb, 0); is0 = bld4(make_rsrc(p.einv0, has_sum ? FULL : 0), cb, 0);
+        if (USE_GATE) { gsc = bld4(make_rsrc(p.escale0, has_gate ? FULL : 0), cb, 0); gsh = bld4(make_rsrc(p.eshift0, has_gate ? FULL : 0), cb, 0); }
     }
-    if (FUSED && p.escale0) { gsc = ld4(p.escale0 + col); gsh = ld4(p.eshift0 + col); }
+    uint32_t pixv[POOL ? 4 : 1], offb[4];    // pixel index and BYTE offset of this lane's float4 in row k; OOB past the tensor
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int rl = rg + 16 * k;
-        const int m = m0 + rl;
-        if (m >= Mc) continue;
-        uint32_t pix = (uint32_t)m;
+        const int m = m0 + rg + 16 * k;
+        const bool valid = m < Mc;
+        uint32_t pix = valid ? (uint32_t)m : 0u;
         if (st != 1) {
-            const uint32_t b = fdiv((uint32_t)m, dHW);
-            const uint32_t rem = (uint32_t)m - b * dHW.d;
+            const uint32_t b = fdiv(pix, dHW);
+            const uint32_t rem = pix - b * dHW.d;
             const uint32_t h2 = fdiv(rem, dW), w2 = rem - h2 * dW.d;
             pix = (b * p.H + (ph + st * h2)) * p.W + (pw + st * w2);
         }
-        const uint32_t off = pix * p.Cin + col;
-        f32x4 v = rd(rl, c4);
-        if (p.addend) v += ld4(p.addend + off);   // may be the output buffer itself: read and written by the same lane
-        if (FUSED) {
-            if (p.ebits) {   // 1 bit / element: words (i4 >> 6) * 4 + component, bit i4 & 63 (bn.hip)
-                const uint32_t i4 = off >> 2;
-                const ulonglong2* wp = reinterpret_cast<const ulonglong2*>(p.ebits + (size_t)(i4 >> 6) * 4);
-                const ulonglong2 w01 = wp[0], w23 = wp[1];
-                const int bit = i4 & 63;
-                v[0] = (w01.x >> bit) & 1 ? v[0] : 0.f; v[1] = (w01.y >> bit) & 1 ? v[1] : 0.f;
-                v[2] = (w23.x >> bit) & 1 ? v[2] : 0.f; v[3] = (w23.y >> bit) & 1 ? v[3] : 0.f;
+        if (POOL) pixv[k] = pix;
+        offb[k] = valid ? (pix * p.Cin + col) * 4u : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t r_y0 = make_rsrc(p.ey0, (has_sum || has_gate) ? FULL : 0);
+    if constexpr (FUSED == 2) {
+        // in-block: one optional tensor, so all four rows go out together
+        f32x4 y0v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y0v[k] = bld4(r_y0, offb[k], 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 v = rd(rg + 16 * k, c4);      // rows past Mc are exact zeros (their operand rows were range-checked loads)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {       // the producer's activation was never stored: its ReLU gate is recomputed from the
+                const bool open = (__builtin_fmaf(y0v[k][e], gsc[e], gsh[e]) > 0.f) | !has_gate;   // pre-BN tensor, one fma as in the forward loader
+                v[e] = open ? v[e] : 0.f;
             }
-            f32x4 y0v = {0, 0, 0, 0};
-            if constexpr (POOL) {
+            sg += v;
+            s0 += (v * (y0v[k] - mu0)) * is0;
+            bst4(r_out, v, offb[k], 0);
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t r_add = make_rsrc(p.addend, (USE_ADD && p.addend) ? FULL : 0);
+        const __amdgpu_buffer_rsrc_t r_bits = make_rsrc(reinterpret_cast<const float*>(p.ebits), has_bits ? FULL : 0);
+        const __amdgpu_buffer_rsrc_t r_y1 = make_rsrc(p.ey1, has_y1 ? FULL : 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rl = rg + 16 * k;
+            f32x4 v = rd(rl, c4);               // rows past Mc are exact zeros (their operand rows were range-checked loads)
+            v += bld4(r_add, offb[k], 0);       // may be the output buffer itself: read and written by the same lane
+            if constexpr (FUSED && POOL) {
                 // dx is the gradient w.r.t. a max-pooled activation: the BatchNorm-backward reductions of the layer BEFORE the pool
                 // see this value at the window's arg-max pixel, gated by the window's ReLU (bit 7): sum g, sum g * xhat(arg-max)
-                const uint32_t bb = fdiv(pix, dHW), rem = pix - bb * dHW.d, ho = fdiv(rem, dW), wo = rem - ho * dW.d;
-                const uint32_t idw = p.epool[off >> 2];
+                if (offb[k] != OOB) {
+                    const uint32_t pix = pixv[k], off = offb[k] >> 2;
+                    const uint32_t bb = fdiv(pix, dHW), rem = pix - bb * dHW.d, ho = fdiv(rem, dW), wo = rem - ho * dW.d;
+                    const uint32_t idw = p.epool[off >> 2];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t byte = (idw >> (8 * e)) & 0xffu, t = byte & 0x7fu, r = t / 3u, sx = t - 3u * r;
+                        const uint32_t apix = (bb * p.epH + 2u * ho - 1u + r) * p.epW + 2u * wo - 1u + sx;
+                        const float gv = (byte & 0x80u) ? v[e] : 0.f;
+                        sg[e] += gv;
+                        s0[e] += (gv * (p.ey0[(size_t)apix * p.Cin + col + e] - mu0[e])) * is0[e];
+                    }
+                }
+            } else if constexpr (FUSED != 0) {
+                // 1 bit / element: words (i4 >> 6) * 4 + component, bit i4 & 63 (bn.hip): 32 contiguous bytes per float4
+                const uint32_t i4 = offb[k] >> 4, bit = i4 & 63u;
+                // of each component's 64-bit word only the half holding this element's bit is fetched (4 registers, not 8)
+                const uint32_t boff = offb[k] != OOB ? (i4 >> 6) * 32u + (bit >> 5) * 4u : OOB;
+                uint32_t wb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wb[e] = __builtin_amdgcn_raw_buffer_load_b32(r_bits, boff, 8 * e, 0);
+                const f32x4 y0v = bld4(r_y0, offb[k], 0), y1v = bld4(r_y1, offb[k], 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const uint32_t byte = (idw >> (8 * e)) & 0xffu, t = byte & 0x7fu, r = t / 3u, sx = t - 3u * r;
-                    const uint32_t apix = (bb * p.epH + 2u * ho - 1u + r) * p.epW + 2u * wo - 1u + sx;
-                    const float gv = (byte & 0x80u) ? v[e] : 0.f;
-                    sg[e] += gv;
-                    s0[e] += (gv * (p.ey0[(size_t)apix * p.Cin + col + e] - mu0[e])) * is0[e];
+                    const bool keep = (((wb[e] >> (bit & 31u)) & 1u) != 0) | !has_bits;
+                    const bool open = !USE_GATE || (__builtin_fmaf(y0v[e], gsc[e], gsh[e]) > 0.f) | !has_gate;
+                    v[e] = (keep & open) ? v[e] : 0.f;
                 }
-                *reinterpret_cast<f32x4*>(p.y + off) = v;
-                continue;
-            }
-            if (p.escale0 || p.esum) y0v = ld4(p.ey0 + off);
-            if (p.escale0) {   // the producer's activation was never stored: its ReLU gate is recomputed from the pre-BN tensor
-#pragma unroll               // with the very expression (one fma) the forward loader used
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(y0v[e], gsc[e], gsh[e]) > 0.f ? v[e] : 0.f;
-            }
-            if (p.esum) {    // BatchNorm-backward partial sums of the consumer(s): sum g, sum g*xhat0 [, sum g*xhat1]
+                // BatchNorm-backward partial sums of the consumer(s): sum g, sum g*xhat0 [, sum g*xhat1] (written only when asked for)
                 sg += v;
                 s0 += (v * (y0v - mu0)) * is0;
-                if (p.ey1) s1 += (v * (ld4(p.ey1 + off) - mu1)) * is1;
+                s1 += v * y1v;       // second consumer: raw sum, centred and scaled after the loop (its mean / invstd are not kept live)
             }
+            bst4(r_out, v, offb[k], 0);
+            // one row's loads in flight at a time: hoisting the next row's five loads over this row's arithmetic does not fit the
+            // 64 registers that keep eight waves per SIMD (the scheduler would spill instead of giving up the overlap)
+            if (FUSED == 1 || FUSED == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        *reinterpret_cast<f32x4*>(p.y + off) = v;
+        if (USE_Y1) {   // sum g * xhat1 = invstd1 * (sum g * y1 - mean1 * sum g), per lane (everything after this is linear)
+            const uint32_t cb = (uint32_t)col * 4u;
+            const f32x4 mu1 = bld4(make_rsrc(p.emean1, has_y1 ? FULL : 0), cb, 0), is1 = bld4(make_rsrc(p.einv1, has_y1 ? FULL : 0), cb, 0);
+            s1 = (s1 - mu1 * sg) * is1;
+        }
     }
     if (FUSED && p.esum) {
         // rows of one channel quad: 4 lanes of the wave (lane bits 4, 5), then the 4 waves through LDS, in wave order
@@ -551,7 +600,7 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
 // KS: the launch carries a K-split tail (stride 1 only; see tile_of_block_split), its own instantiation like k_conv_fwd's
 // POOL: pool-mode reductions in the epilogue (osi_dgrad_fusion.pool_idx) — one launch per step, its own instantiation so that the
 // workhorse keeps its 8 waves per SIMD
-template <int WM, int WN, int NST, bool FUSED, bool KS = false, bool POOL = false>
+template <int WM, int WN, int NST, int FUSED, bool KS = false, bool POOL = false>
 __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ? 8 : 4)) : 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0) {
     static_assert(!KS || (WM == 1 && WN == 1 && NST == 1), "the K-split tail is built for the single-buffered 64x64 tile");
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -1285,7 +1334,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_tail_fixup(ConvP p) {
 
 // Fix-up pass of an input-gradient launch with a K-split tail (stride 1): per remainder tile, the splits are added in split order
 // and the tile goes through the very epilogue of the convolution kernel (dgrad_epilogue64).
-template <bool FUSED>
+template <int FUSED>
 __global__ __launch_bounds__(256) void k_conv_dgrad_tail_fixup(ConvP p) {
     __shared__ float red[4 * 64 * 3];
     const int tile = blockIdx.x;
@@ -1440,7 +1489,7 @@ static int launch_fwd(ConvP p, hipStream_t st) {
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
-template <int WM, int WN, int NST, bool FUSED, bool POOL = false>
+template <int WM, int WN, int NST, int FUSED, bool POOL = false>
 static int launch_dgrad_impl(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int s = p.stride;
@@ -1462,7 +1511,7 @@ static int launch_dgrad_impl(ConvP p, hipStream_t st) {
     return OSI_OK;
 }
 // 64x64 single-buffered input gradient with a K-split tail (stride 1): convolution launch + fix-up pass
-template <bool FUSED>
+template <int FUSED>
 static int launch_dgrad_split(ConvP p, const TailPlan& tp, float* slab, hipStream_t st) {
     p.cHW[0] = make_fastdiv((uint32_t)(p.H * p.W)); p.cW[0] = make_fastdiv((uint32_t)p.W);
     p.unit = (p.R == 1 && p.S == 1 && p.pad == 0) ? 1 : 0;
@@ -1479,13 +1528,23 @@ static int launch_dgrad_split(ConvP p, const TailPlan& tp, float* slab, hipStrea
     return OSI_OK;
 }
 
+static int dgrad_flavour(const ConvP& p) {
+    if (!p.addend && !p.ebits && !p.ey1) return 2;     // in-block: gate recomputed from y0 and / or sums over y0
+    if (!p.escale0) return 3;                          // block input: addend, bitmask, sums over y0 (and y1)
+    return 1;
+}
 template <int WM, int WN, int NST = 2>
 static int launch_dgrad(ConvP p, hipStream_t st) {
     // the fused epilogue (mask / BatchNorm reductions) is its own instantiation so that plain launches keep the small one
     if (p.ebits || p.esum || p.escale0) {
         if (NST != 1 || WM != 1) return OSI_ERR_ARG;   // fusion is built for the single-buffered 64-row tiles the executor uses
-        if (p.epool) return WN == 1 ? launch_dgrad_impl<1, 1, 1, true, true>(p, st) : OSI_ERR_ARG;
-        return launch_dgrad_impl<1, WN, 1, true>(p, st);
+        if (p.epool) return WN == 1 ? launch_dgrad_impl<1, 1, 1, 1, true>(p, st) : OSI_ERR_ARG;
+        if (WN == 1) {   // the two fusion flavours the executor issues have their own instantiations (see dgrad_epilogue64)
+            const int fl = dgrad_flavour(p);
+            if (fl == 2) return launch_dgrad_impl<1, 1, 1, 2>(p, st);
+            if (fl == 3) return launch_dgrad_impl<1, 1, 1, 3>(p, st);
+        }
+        return launch_dgrad_impl<1, WN, 1, 1>(p, st);
     }
     return launch_dgrad_impl<WM, WN, NST, false>(p, st);
 }
@@ -1830,7 +1889,11 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
             // ragged last round split along K when the caller's workspace has room for the slab behind the partial sums
             const TailPlan tp = dgrad_tail_plan(d);
             if (!f->pool_idx && tile == OSI_TILE_64x64_S1 && tp.S > 1 && f->partials_bytes >= (dgrad_partial_floats(d) + tail_slab_floats(tp)) * sizeof(float))
-                return launch_dgrad_split<true>(p, tp, f->partials + dgrad_partial_floats(d), st);
+            {
+                float* slab = f->partials + dgrad_partial_floats(d);
+                const int fl = dgrad_flavour(p);
+                return fl == 2 ? launch_dgrad_split<2>(p, tp, slab, st) : fl == 3 ? launch_dgrad_split<3>(p, tp, slab, st) : launch_dgrad_split<1>(p, tp, slab, st);
+            }
         }
     }
     switch (tile) {
