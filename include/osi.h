@@ -74,7 +74,10 @@ int osi_conv_fwd_act(const osi_conv_desc* d, const float* x, const float* in_sca
 int osi_conv_fwd_act2(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* res,
                       const float* w, float* y, int tile, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block,
                       osi_stream_t stream);
-/* dx (+)= conv2d_input_grad(dy, w). accumulate != 0 adds into dx (skip-connection sum). Cout % 32 == 0, Cin % 64 == 0. */
+/* dx (+)= conv2d_input_grad(dy, w). accumulate = 1 adds into dx (skip-connection sum); accumulate = 2 ("sparse", ABI 4) writes
+ * only the input pixels some filter tap reaches and leaves every other element of dx UNTOUCHED (a stride-2 1x1 convolution reaches
+ * the pixels with even h and even w: a quarter of the tensor) — for a consumer that knows the pattern, see
+ * osi_dgrad_fusion.addend_stride. Cout % 32 == 0, Cin % 64 == 0. */
 int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, int tile,
                    osi_stream_t stream);
 /* Input gradient with a fused epilogue: dx = relu_mask . (conv2d_input_grad(dy, w) + addend), i.e. the gradient already passed
@@ -102,6 +105,9 @@ typedef struct {
      * Finish them with osi_bn_backward_reduce. */
     const void* pool_idx;
     int pool_H, pool_W;
+    /* ABI 4. 0 / 1: `addend` is dense. 2: `addend` holds values only at pixels with even h AND even w (what osi_conv_dgrad with
+     * accumulate = 2 wrote for a stride-2 1x1 convolution); every other pixel of it is never read and counts as zero. */
+    int addend_stride;
 } osi_dgrad_fusion;
 size_t osi_conv_dgrad_fused_workspace(const osi_conv_desc* d);
 int osi_conv_dgrad_fused(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,

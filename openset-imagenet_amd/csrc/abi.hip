@@ -31,7 +31,7 @@ int* tuning_slot(const char* name) {
 }  // namespace
 
 extern "C" {
-int osi_abi_version(void) { return 3; }   // 3: debug gate read-out, executor geometry, direct / fused stem kernels, const crop table
+int osi_abi_version(void) { return 4; }   // 4: osi_dgrad_fusion.addend_stride, osi_conv_dgrad accumulate = 2 (3: gate read-out, geometry, stem kernels)
 int osi_set_tuning(const char* name, int value) {
     int* s = tuning_slot(name);
     if (!s) return OSI_ERR_ARG;

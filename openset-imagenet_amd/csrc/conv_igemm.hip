@@ -55,6 +55,8 @@ struct ConvP {
     const float* ey1;
     const float *emean0, *einv0, *emean1, *einv1;  // batch mean / invstd of the consumer BatchNorm(s): xhat = (y - mean) * invstd
     const float *escale0, *eshift0;                // ReLU gate recomputed from ey0 (no bitmask): on where ey0 * scale + shift > 0
+    int skip_empty;                                // dgrad: parity classes no filter tap reaches write nothing (osi_conv_dgrad accumulate = 2)
+    int eadd_even;                                 // dgrad epilogue: the addend exists only at pixels with even h and even w
     const uint32_t* epool;                         // pool mode: arg-max bytes of the max-pool whose output this conv reads; ey0 is the
     int epH, epW;                                  // pre-pool tensor [B][epH][epW][Cin] (osi_dgrad_fusion.pool_idx)
     float* esum;
@@ -515,7 +517,13 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
         for (int k = 0; k < 4; ++k) {
             const int rl = rg + 16 * k;
             f32x4 v = rd(rl, c4);               // rows past Mc are exact zeros (their operand rows were range-checked loads)
-            v += bld4(r_add, offb[k], 0);       // may be the output buffer itself: read and written by the same lane
+            uint32_t aoff = offb[k];
+            if (p.eadd_even) {                  // sparse addend (a stride-2 1x1 branch wrote only the even-even pixels): elsewhere
+                const uint32_t pix = (uint32_t)(m0 + rl);                   // nothing is read (st == 1 here: pix = m = b*H*W + h*W + w)
+                const uint32_t b = fdiv(pix, dHW), rem = pix - b * dHW.d, h = fdiv(rem, dW), w = rem - h * dW.d;
+                aoff = (((h | w) & 1u) != 0u || offb[k] == OOB) ? OOB : offb[k];
+            }
+            v += bld4(r_add, aoff, 0);          // may be the output buffer itself: read and written by the same lane
             if constexpr (FUSED && POOL) {
                 // dx is the gradient w.r.t. a max-pooled activation: the BatchNorm-backward reductions of the layer BEFORE the pool
                 // see this value at the window's arg-max pixel, gated by the window's ReLU (bit 7): sum g, sum g * xhat(arg-max)
@@ -637,6 +645,7 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ?
     const int rb = (ph + p.pad) % st, sb = (pw + p.pad) % st;
     const int nR = rb < p.R ? (p.R - rb + st - 1) / st : 0;
     const int nS = sb < p.S ? (p.S - sb + st - 1) / st : 0;
+    if (p.skip_empty && nR * nS == 0) return;   // sparse form: no tap reaches this parity class, its pixels are not written at all
 
     const FastDiv dHW = p.cHW[cls], dW = p.cW[cls];
     // a_base = offset of the dY pixel reached through the class's first tap (jr = js = 0); a_taps = bit (jr*nS+js) set when
@@ -1822,11 +1831,12 @@ static int dgrad_rows(int tile) {
     return (tile == OSI_TILE_128x128 || tile == OSI_TILE_128x64 || tile == OSI_TILE_128x128_S1 || tile == OSI_TILE_128x64_S1) ? 128 : 64;
 }
 static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,
-                           const osi_dgrad_fusion* f, int tile, int* P, osi_stream_t stream);
+                           const osi_dgrad_fusion* f, int tile, int* P, osi_stream_t stream, bool sparse = false);
 
 int osi_conv_dgrad(const osi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, int tile,
                    osi_stream_t stream) {
-    return conv_dgrad_impl(d, dy, w, dx, accumulate ? dx : nullptr, nullptr, tile, nullptr, stream);
+    OSI_REQUIRE(accumulate >= 0 && accumulate <= 2);
+    return conv_dgrad_impl(d, dy, w, dx, accumulate == 1 ? dx : nullptr, nullptr, tile, nullptr, stream, accumulate == 2);
 }
 
 // floats of the partial-sum part of the fused input-gradient workspace, rounded to 256 B: the slab of a K-split tail starts behind it
@@ -1853,13 +1863,14 @@ int osi_conv_dgrad_fused(const osi_conv_desc* d, const float* dy, const float* w
 }
 
 static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,
-                           const osi_dgrad_fusion* f, int tile, int* P, osi_stream_t stream) {
+                           const osi_dgrad_fusion* f, int tile, int* P, osi_stream_t stream, bool sparse) {
     OSI_REQUIRE(desc_ok(d) && dy && w && dx);
     OSI_REQUIRE(!is_stem(d));  // the image needs no gradient (train.py:128-139: input is a leaf without grad)
     OSI_REQUIRE(d->Cout % BK == 0 && d->Cin % 64 == 0 && d->stride <= 2);
     hipStream_t st = (hipStream_t)stream;
     ConvP p = make_p(d);
     p.x = dy; p.w = w; p.y = dx; p.addend = addend;
+    p.skip_empty = sparse ? 1 : 0;
     p.x_bytes = (int)((size_t)d->B * d->Ho * d->Wo * d->Cout * 4);
     p.w_bytes = (int)((size_t)d->Cout * p.Ktot * 4);
     // Measured (profiles/conv_layers_r01.txt and the full step): with buffer loads the 64x64 single-buffered tile wins or ties
@@ -1874,6 +1885,11 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
             p.epool = (const uint32_t*)f->pool_idx; p.epH = f->pool_H; p.epW = f->pool_W;
         }
         OSI_REQUIRE(!f->scale0 || (!f->relu_mask && f->shift0 && f->y0));   // one gate source: the bitmask, or y0 * scale0 + shift0 > 0
+        OSI_REQUIRE(f->addend_stride >= 0 && f->addend_stride <= 2);
+        if (f->addend_stride == 2) {   // sparse addend: stride-1 convolution, 64x64 tiles, an addend, no pool mode
+            OSI_REQUIRE(addend && d->stride == 1 && !f->pool_idx && (tile == OSI_TILE_AUTO || tile == OSI_TILE_64x64_S1) && !g_osi_tuning.dgrad_wide);
+            p.eadd_even = 1;
+        }
         p.ebits = (const unsigned long long*)f->relu_mask;
         p.escale0 = f->scale0; p.eshift0 = f->shift0;
         if (f->scale0) p.ey0 = f->y0;

@@ -152,6 +152,7 @@ struct osi_resnet50 {
     const float* x4_ext = nullptr;   // external NHWC4 input bound by osi_resnet50_bind_input_nhwc4 (consumed by one forward)
     const float* x4_cur = nullptr;   // input of the step in flight (forward sets it, the stem weight gradient reads it)
     bool stem_pool_stats = true;     // option "stem_pool_stats": bn1's backward reductions come out of layer1.0.conv1's dgrad epilogue
+    bool ds_sparse = true;           // option "ds_sparse": stride-2 shortcut gradients write / are read at the even-even pixels only
     int stem_stats_P = 0;            // > 0: bn1's backward partial sums wait in dg_ws (left by the pool-mode epilogue of layer1.0.conv1's dgrad)
     bool stem_fused = true;          // option "stem_fused": conv1's weight gradient builds dY in its operand loader (osi_stem_wgrad_fused)
                                      // behind the BatchNorm reductions: no 112x112x64 gradient tensor, no apply pass (step -0.15 ms)
@@ -627,7 +628,7 @@ static int bn_bwd_fused(osi_resnet50* n, int ci, const float* params, float* gra
 // dgrad of conv `ci` (dy in buffer dyi) into buffer dxi, adding buffer addi (-1: none), with the epilogue fused for the layer
 // that produced this conv's input: its ReLU bitmask and the BatchNorm reductions of conv `pc` (and `pd`, the downsample twin).
 static int dgrad_fused(osi_resnet50* n, int ci, const float* params, float* ws, int dyi, int dxi, int addi, int pc, int pd,
-                       hipStream_t st) {
+                       hipStream_t st, bool add_even = false) {
     Conv& c = n->convs[ci];
     Conv& p0 = n->convs[pc];
     BN& b0 = n->bns[p0.bn];
@@ -641,6 +642,7 @@ static int dgrad_fused(osi_resnet50* n, int ci, const float* params, float* ws, 
         f.y1 = ws + p1.y; f.mean1 = ws + b1.mean; f.invstd1 = ws + b1.invstd;
     }
     f.partials = ws + n->dg_ws; f.partials_bytes = n->dg_ws_bytes;
+    f.addend_stride = add_even ? 2 : 1;
     int P = 0;
     OSI_TRY(before_dgrad(n, st));
     OSI_TRY(osi_conv_dgrad_fused(&c.d, ws + n->scratch[dyi], params + c.w_off, ws + n->scratch[dxi],
@@ -659,6 +661,10 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
     Conv &c1 = n->convs[k.c1], &c2 = n->convs[k.c2], &c3 = n->convs[k.c3];
     const float* x = ws + k.x_in;
     const bool has_ds = k.ds >= 0;
+    // A stride-2 1x1 shortcut reaches only the even-even pixels of the block input: its input gradient writes just those (a quarter
+    // of the tensor, no zero fill) and conv1's input gradient, which completes the sum in place, reads the addend only there.
+    // bi == 0 keeps the dense form (pool mode); so does the wide-tile A/B switch.
+    const bool ds_sparse = has_ds && bi > 0 && n->ds_sparse && n->convs[k.ds].d.stride == 2 && n->convs[k.ds].d.R == 1;
     int go = n->cur_grad;
     int d3 = -1, dxbase = -1;
     if (n->go_fused) {
@@ -670,7 +676,7 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
             OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
             dxbase = n->take(st);
             if (dxbase < 0) return dxbase;
-            OSI_TRY(dgrad_plain(n, &cd.d, S(t1), params + cd.w_off, S(dxbase), 0, st));
+            OSI_TRY(dgrad_plain(n, &cd.d, S(t1), params + cd.w_off, S(dxbase), ds_sparse ? 2 : 0, st));
             n->give(t1);
         }
         d3 = n->take(st);
@@ -691,7 +697,7 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
                                               n->bn_ws_bytes, st));
             OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
             OSI_TRY(wgrad(n, k.ds, grads, ws, t1, x, st));
-            OSI_TRY(dgrad_plain(n, &cd.d, S(t1), params + cd.w_off, S(dxbase), 0, st));
+            OSI_TRY(dgrad_plain(n, &cd.d, S(t1), params + cd.w_off, S(dxbase), ds_sparse ? 2 : 0, st));
             n->give(t1);
         }
         BN& b3 = n->bns[c3.bn];
@@ -720,7 +726,7 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
         Block& pk = n->blocks[bi - 1];
         int dxn = has_ds ? dxbase : n->take(st);   // downsample case: add in place (each lane reads then writes its own element)
         if (dxn < 0) return dxn;
-        OSI_TRY(dgrad_fused(n, k.c1, params, ws, t3, dxn, dxbase, pk.c3, pk.ds, st));
+        OSI_TRY(dgrad_fused(n, k.c1, params, ws, t3, dxn, dxbase, pk.c3, pk.ds, st, ds_sparse));
         if (dxn != dxbase) n->give(dxbase);
         n->cur_grad = dxn;
         n->go_fused = true;
@@ -954,6 +960,7 @@ int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
     else if (!strcmp(name, "fwd_recompute")) n->fwd_recompute = value != 0;
     else if (!strcmp(name, "stem_fused")) n->stem_fused = value != 0;
     else if (!strcmp(name, "stem_pool_stats")) n->stem_pool_stats = value != 0;
+    else if (!strcmp(name, "ds_sparse")) n->ds_sparse = value != 0;
     else if (!strcmp(name, "side_priority_normal")) {
         if (n->side) return OSI_ERR_STATE;   // the side stream already exists with the other priority
         n->side_prio_normal = value != 0;

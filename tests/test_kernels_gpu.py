@@ -449,7 +449,70 @@ class _Fusion(ctypes.Structure):
     _fields_ = [("relu_mask", ctypes.c_void_p), ("y0", ctypes.c_void_p), ("mean0", ctypes.c_void_p), ("invstd0", ctypes.c_void_p),
                 ("y1", ctypes.c_void_p), ("mean1", ctypes.c_void_p), ("invstd1", ctypes.c_void_p), ("partials", ctypes.c_void_p),
                 ("partials_bytes", ctypes.c_size_t), ("scale0", ctypes.c_void_p), ("shift0", ctypes.c_void_p),
-                ("pool_idx", ctypes.c_void_p), ("pool_H", ctypes.c_int), ("pool_W", ctypes.c_int)]   # osi_dgrad_fusion (ABI 2)
+                ("pool_idx", ctypes.c_void_p), ("pool_H", ctypes.c_int), ("pool_W", ctypes.c_int), ("addend_stride", ctypes.c_int)]   # osi_dgrad_fusion (ABI 4)
+
+
+@pytest.mark.parametrize("H,B,two,tail", [(12, 3, True, 0), (14, 5, False, 1), (9, 2, True, 0)])
+def test_sparse_shortcut_gradient_and_even_pixel_addend(cuda, H, B, two, tail):
+    """A stride-2 1x1 shortcut reaches only the even-even pixels of its input: osi_conv_dgrad(accumulate = 2) writes just those and
+    leaves the rest of dx untouched, and osi_conv_dgrad_fused with addend_stride = 2 reads the addend only there. Both together equal
+    the dense pair (zero-filled shortcut gradient, dense addend) bit for bit: output, and the BatchNorm partial sums."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    Cin, Cds, C1 = 128, 256, 128         # block input channels; shortcut 1x1 s2 Cin -> Cds; conv1 1x1 s1 Cin -> C1 (4 K tiles)
+    g = torch.Generator().manual_seed(H * 7 + B)
+    dds = N.ConvDesc.make(B, H, H, Cin, Cds, 1, 2, 0)
+    d1 = N.ConvDesc.make(B, H, H, Cin, C1, 1, 1, 0)
+    M = B * H * H
+    dy_ds = torch.randn(B, dds.Ho, dds.Wo, Cds, generator=g).to(cuda)
+    w_ds = (torch.randn(Cds, 1, 1, Cin, generator=g) / Cds ** 0.5).to(cuda)
+    dy1 = torch.randn(B, H, H, C1, generator=g).to(cuda)
+    w1 = (torch.randn(C1, 1, 1, Cin, generator=g) / C1 ** 0.5).to(cuda)
+    # the sparse shortcut gradient: even-even pixels written, everything else untouched
+    dense = torch.full((B, H, H, Cin), float("nan"), device=cuda)
+    N.check(L.osi_conv_dgrad(ctypes.byref(dds), N.ptr(dy_ds), N.ptr(w_ds), N.ptr(dense), 0, 0, T.S()))
+    sparse = torch.full((B, H, H, Cin), float("nan"), device=cuda)
+    N.check(L.osi_conv_dgrad(ctypes.byref(dds), N.ptr(dy_ds), N.ptr(w_ds), N.ptr(sparse), 2, 0, T.S()))
+    torch.cuda.synchronize()
+    assert torch.equal(sparse[:, ::2, ::2], dense[:, ::2, ::2])
+    untouched = torch.ones(H, H, dtype=torch.bool); untouched[::2, ::2] = False
+    assert bool(torch.isnan(sparse[:, untouched.to(cuda)]).all()) and float(dense[:, untouched.to(cuda)].abs().max()) == 0.0
+    assert L.osi_conv_dgrad(ctypes.byref(dds), N.ptr(dy_ds), N.ptr(w_ds), N.ptr(sparse), 3, 0, T.S()) != 0
+    # the consumer: conv1's input gradient completes the sum in place, masks it and emits the BatchNorm reductions
+    ys = [(torch.randn(M, Cin, generator=g) * 2 + 1).to(cuda) for _ in range(2 if two else 1)]
+    stats = [[(torch.randn(Cin, generator=g) + 1).to(cuda), (torch.rand(Cin, generator=g) + 0.5).to(cuda)] for _ in ys]   # mean, invstd
+    mask = torch.randint(0, 256, (L.osi_bn_relu_mask_bytes(M, Cin),), generator=g, dtype=torch.uint8).to(cuda)
+    outs = []
+    N.check(L.osi_set_tuning(b"tail_split", tail))
+    if tail:    # a plan that splits this small launch: 32 tiles on "24 CUs" = one full round + 8 remainder tiles cut in 3
+        N.check(L.osi_set_tuning(b"tail_mint", 1)); N.check(L.osi_set_tuning(b"tail_smax", 32)); N.check(L.osi_set_tuning(b"tail_cus", 24))
+    try:
+        pb = L.osi_conv_dgrad_fused_workspace(ctypes.byref(d1))     # includes the slab of the plan in force
+        for buf, stride in ((dense.clone(), 1), (sparse.clone(), 2)):
+            parts = torch.full((pb // 4,), float("nan"), device=cuda)
+            f = _Fusion(mask.data_ptr(), ys[0].data_ptr(), stats[0][0].data_ptr(), stats[0][1].data_ptr(),
+                        ys[1].data_ptr() if two else None, stats[1][0].data_ptr() if two else None, stats[1][1].data_ptr() if two else None,
+                        parts.data_ptr(), pb, None, None, None, 0, 0, stride)
+            P = ctypes.c_int()
+            N.check(L.osi_conv_dgrad_fused(ctypes.byref(d1), N.ptr(dy1), N.ptr(w1), N.ptr(buf), N.ptr(buf), ctypes.byref(f), 0, ctypes.byref(P), T.S()))
+            torch.cuda.synchronize()
+            outs.append((buf, None, parts.clone()))
+    finally:
+        N.check(L.osi_set_tuning(b"tail_split", 1))
+        if tail:
+            N.check(L.osi_set_tuning(b"tail_mint", 16)); N.check(L.osi_set_tuning(b"tail_smax", 8)); N.check(L.osi_set_tuning(b"tail_cus", 0))
+    assert not bool(torch.isnan(outs[1][0]).any())
+    assert torch.equal(outs[0][0], outs[1][0]), "even-pixel addend must give the dense result bit for bit"
+    k = (3 if two else 2) * P.value * Cin      # the partial sums in use (sum g, sum g*xhat0 [, sum g*xhat1]); the rest is workspace
+    assert torch.equal(outs[0][2][:2 * P.value * Cin], outs[1][2][:2 * P.value * Cin])
+    if two:
+        a, b = outs[0][2][2 * P.value * Cin:k], outs[1][2][2 * P.value * Cin:k]
+        assert torch.equal(a, b) and not bool(torch.isnan(a).any())
+    # stride-2 addends are refused where they make no sense: a strided convolution, no addend
+    f = _Fusion(mask.data_ptr(), ys[0].data_ptr(), stats[0][0].data_ptr(), stats[0][1].data_ptr(), None, None, None, parts.data_ptr(), pb,
+                None, None, None, 0, 0, 2)
+    assert L.osi_conv_dgrad_fused(ctypes.byref(d1), N.ptr(dy1), N.ptr(w1), N.ptr(buf), None, ctypes.byref(f), 0, ctypes.byref(P), T.S()) != 0
 
 
 @pytest.mark.parametrize("Cin,Cout,k,stride,H,B,two", [(64, 64, 1, 1, 14, 3, False), (128, 64, 3, 1, 9, 3, True), (256, 128, 3, 2, 9, 2, False),
