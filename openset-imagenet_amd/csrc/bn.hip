@@ -291,13 +291,13 @@ __global__ __launch_bounds__(NT) void k_bn_apply(const f32x4* __restrict__ y, co
     const size_t step = (size_t)gridDim.x * NT;
     for (; i < n4; i += step) {
         int c4 = (int)(i % (size_t)c4n);
-        const f32x4 yv = y[i], sc = scale[c4], sh = shift[c4];
+        const f32x4 yv = __builtin_nontemporal_load(y + i), sc = scale[c4], sh = shift[c4];
         f32x4 v;   // one fma per element: the same expression the fused conv loaders and the dgrad gate evaluate
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(yv[e], sc[e], sh[e]);
-        if (RES == 1) v += res[i];
+        if (RES == 1) v += __builtin_nontemporal_load(res + i);
         if (RES == 2) {
-            const f32x4 rv = res[i], rs = rscale[c4], rh = rshift[c4];
+            const f32x4 rv = __builtin_nontemporal_load(res + i), rs = rscale[c4], rh = rshift[c4];
             f32x4 t;
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] = __builtin_fmaf(rv[e], rs[e], rh[e]);
@@ -506,9 +506,9 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const f32x4* dA /* may alia
     const size_t step = (size_t)gridDim.x * NT;
     for (; i < n4; i += step) {
         int c4 = (int)(i % (size_t)c4n);
-        f32x4 gv = MODE == 3 ? pool_gather(dA, ps, (uint32_t)(i / (size_t)c4n), c4, c4n) : masked<MODE>(dA[i], msk, i);
+        f32x4 gv = MODE == 3 ? pool_gather(dA, ps, (uint32_t)(i / (size_t)c4n), c4, c4n) : masked<MODE>(__builtin_nontemporal_load(dA + i), msk, i);
         f32x4 is = invstd[c4];
-        f32x4 xh = (y[i] - mean[c4]) * is;
+        f32x4 xh = (__builtin_nontemporal_load(y + i) - mean[c4]) * is;
         f32x4 r = (gv - c1[c4] - xh * c2[c4]) * (gamma[c4] * is);
         if (EMITG) gout[i] = gv;
         dy[i] = r;
