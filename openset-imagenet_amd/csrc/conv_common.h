@@ -15,10 +15,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int 
 __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-// the same with the non-temporal hint (aux bit 1 = NT on gfx94x / gfx950): operands read exactly once
-__device__ __forceinline__ f32x4 bld4nt(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2));
-}
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 bld4u(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));

@@ -523,7 +523,7 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
                 const uint32_t b = fdiv(pix, dHW), rem = pix - b * dHW.d, h = fdiv(rem, dW), w = rem - h * dW.d;
                 aoff = (((h | w) & 1u) != 0u || offb[k] == OOB) ? OOB : offb[k];
             }
-            v += bld4nt(r_add, aoff, 0);        // may be the output buffer itself: read and written by the same lane; read once
+            v += bld4(r_add, aoff, 0);          // may be the output buffer itself: read and written by the same lane
             if constexpr (FUSED && POOL) {
                 // dx is the gradient w.r.t. a max-pooled activation: the BatchNorm-backward reductions of the layer BEFORE the pool
                 // see this value at the window's arg-max pixel, gated by the window's ReLU (bit 7): sum g, sum g * xhat(arg-max)
