@@ -517,12 +517,10 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
         for (int k = 0; k < 4; ++k) {
             const int rl = rg + 16 * k;
             f32x4 v = rd(rl, c4);               // rows past Mc are exact zeros (their operand rows were range-checked loads)
-            uint32_t aoff = offb[k];
-            if (p.eadd_even) {                  // sparse addend (a stride-2 1x1 branch wrote only the even-even pixels): elsewhere
-                const uint32_t pix = (uint32_t)(m0 + rl);                   // nothing is read (st == 1 here: pix = m = b*H*W + h*W + w)
-                const uint32_t b = fdiv(pix, dHW), rem = pix - b * dHW.d, h = fdiv(rem, dW), w = rem - h * dW.d;
-                aoff = (((h | w) & 1u) != 0u || offb[k] == OOB) ? OOB : offb[k];
-            }
+            // sparse addend (a stride-2 1x1 branch wrote only the even-even pixels): elsewhere nothing is read. Computed without a
+            // branch (st == 1 in that mode: pix = m = b*H*W + h*W + w), so that the rows stay one basic block
+            const uint32_t apix = (uint32_t)(m0 + rl), ab = fdiv(apix, dHW), arem = apix - ab * dHW.d, ah = fdiv(arem, dW), aw = arem - ah * dW.d;
+            const uint32_t aoff = (((ah | aw) & (uint32_t)p.eadd_even) != 0u) ? OOB : offb[k];   // eadd_even is 0 or 1: a mask, not a branch
             v += bld4(r_add, aoff, 0);          // may be the output buffer itself: read and written by the same lane
             if constexpr (FUSED && POOL) {
                 // dx is the gradient w.r.t. a max-pooled activation: the BatchNorm-backward reductions of the layer BEFORE the pool
@@ -563,7 +561,7 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
             bst4(r_out, v, offb[k], 0);
             // one row's loads in flight at a time: hoisting the next row's five loads over this row's arithmetic does not fit the
             // 64 registers that keep eight waves per SIMD (the scheduler would spill instead of giving up the overlap)
-            if (FUSED == 1 || FUSED == 3) __builtin_amdgcn_sched_barrier(0);
+            if (FUSED == 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (USE_Y1) {   // sum g * xhat1 = invstd1 * (sum g * y1 - mean1 * sum g), per lane (everything after this is linear)
             const uint32_t cb = (uint32_t)col * 4u;

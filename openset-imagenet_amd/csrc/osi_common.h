@@ -60,10 +60,11 @@ static inline FastDiv make_fastdiv(uint32_t d) {
     return f;
 }
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
-    if (f.d == 1) return n;
     uint32_t t = __umulhi(n, f.mul);
-    // q = (t + n) >> sh without overflow: ((n - t) >> 1) + t, then >> (sh-1)
-    return (((n - t) >> 1) + t) >> (f.sh - 1);
+    // q = (t + n) >> sh without overflow: ((n - t) >> 1) + t, then >> (sh-1). d == 1 (mul = sh = 0) is a select, not an early
+    // return: a branch here, uniform as it is, splits every caller's basic block and with it the compiler's load scheduling
+    const uint32_t q = (((n - t) >> 1) + t) >> ((f.sh - 1) & 31);
+    return f.d == 1 ? n : q;
 }
 
 // Chan/Welford merge of two (count, mean, M2) triples: a <- a (+) b. Exact in the counts, no E[x^2]-E[x]^2 cancellation.
