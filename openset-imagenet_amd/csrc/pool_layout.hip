@@ -67,19 +67,27 @@ __global__ __launch_bounds__(256) void k_bn_relu_maxpool_fwd(const f32x4* __rest
     f32x4 best = {NEG, NEG, NEG, NEG};
     uint32_t bi[4] = {0, 0, 0, 0};
     bool first[4] = {true, true, true, true};
+    // the nine window loads go out together (coordinates clamped into the image, validity applied afterwards): with the load inside
+    // the bounds test every tap was its own basic block and its own memory round trip
+    f32x4 win[9];
+    bool ok[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            int h = ho * 2 - 1 + r, w = wo * 2 - 1 + s;
-            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-                f32x4 v = y[((size_t)(b * H + h) * W + w) * C4 + c4] * sc + sh;      // same expression as k_bn_apply
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (first[k] || v[k] > best[k]) { best[k] = v[k]; bi[k] = r * 3 + s; first[k] = false; }
-            }
+            const int h = ho * 2 - 1 + r, w = wo * 2 - 1 + s;
+            ok[r * 3 + s] = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+            win[r * 3 + s] = y[((size_t)(b * H + hc) * W + wc) * C4 + c4];
         }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        f32x4 v = win[j] * sc + sh;      // same expression as k_bn_apply
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ok[j] && (first[k] || v[k] > best[k])) { best[k] = v[k]; bi[k] = j; first[k] = false; }
+    }
     pooled[i] = best;
 #pragma unroll
     for (int k = 0; k < 4; ++k) bi[k] |= best[k] > 0.f ? 0x80u : 0u;
