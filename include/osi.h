@@ -38,7 +38,7 @@ const char* osi_strerror(int code);
  * never consult the environment. Names: "wgrad_tile" (64 = force 64x64 weight-gradient tiles), "wgrad_blocks" (split-K footprint
  * budget), "wgrad_nst" (LDS stages, 1|2), "wgrad_group" (weight-gradient block-to-XCD mapping, 0|1|2), "wgrad3" (3x3 stride-1 weight gradients on the
  * all-taps kernel, 0|1), "wgrad3_blocks" (its split-K workgroup budget), "fwd_wide" / "dgrad_wide" (force 64x128 tiles, A/B only), "bn_grid" (grid cap of the
- * BatchNorm stream kernels), "bn_single_p" (BatchNorm statistics: one merge launch up to this many row-tile partials), "tail_gain" / "tail_qmax" (balanced remainder: least modelled gain in percent / most full rounds for a launch to be split), "bn_wide_p" (one 1024-thread merge launch up to this many partials, forward statistics and backward sums; 0 = always two levels). Unknown name / out-of-range value -> OSI_ERR_ARG. Not meant to be changed while launches are in flight. */
+ * BatchNorm stream kernels), "bn_single_p" (BatchNorm statistics: one merge launch up to this many row-tile partials), "tail_gain" / "tail_qmax" (balanced remainder: least modelled gain in percent / most full rounds for a launch to be split), "bn_grid_bwd" (the same cap for the backward apply kernels), "bn_wide_p" (one 1024-thread merge launch up to this many partials, forward statistics and backward sums; 0 = always two levels). Unknown name / out-of-range value -> OSI_ERR_ARG. Not meant to be changed while launches are in flight. */
 int osi_set_tuning(const char* name, int value);
 int osi_get_tuning(const char* name, int* value);
 

@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1, /*tail_gain*/ 8, /*tail_qmax*/ 8, /*bn_wide_p*/ 2048};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1, /*tail_gain*/ 8, /*tail_qmax*/ 8, /*bn_grid_bwd*/ 1024, /*bn_wide_p*/ 2048};
 
 namespace {
 int* tuning_slot(const char* name) {
@@ -24,6 +24,7 @@ int* tuning_slot(const char* name) {
     if (!strcmp(name, "tail_mint")) return &g_osi_tuning.tail_mint;
     if (!strcmp(name, "stem_direct")) return &g_osi_tuning.stem_direct;
     if (!strcmp(name, "bn_wide_p")) return &g_osi_tuning.bn_wide_p;
+    if (!strcmp(name, "bn_grid_bwd")) return &g_osi_tuning.bn_grid_bwd;
     if (!strcmp(name, "tail_gain")) return &g_osi_tuning.tail_gain;
     if (!strcmp(name, "tail_qmax")) return &g_osi_tuning.tail_qmax;
     return nullptr;
@@ -37,7 +38,7 @@ int osi_set_tuning(const char* name, int value) {
     if (!s) return OSI_ERR_ARG;
     if ((s == &g_osi_tuning.wgrad_blocks || s == &g_osi_tuning.wgrad3_blocks) && value < 1) return OSI_ERR_ARG;
     if (s == &g_osi_tuning.wgrad_nst && value != 1 && value != 2) return OSI_ERR_ARG;
-    if (s == &g_osi_tuning.bn_grid && value < 1) return OSI_ERR_ARG;
+    if ((s == &g_osi_tuning.bn_grid || s == &g_osi_tuning.bn_grid_bwd) && value < 1) return OSI_ERR_ARG;
     if (s == &g_osi_tuning.bn_single_p && value < 1) return OSI_ERR_ARG;
     if (s == &g_osi_tuning.bn_wide_p && value < 0) return OSI_ERR_ARG;
     *s = value;

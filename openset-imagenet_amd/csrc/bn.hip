@@ -527,8 +527,8 @@ static int rows_per_block(int M, int C, int& P) {
 }
 // 4 workgroups (16 waves) per CU stream at the HBM rate and leave half of every CU's wave slots, and all of its LDS, to the
 // weight-gradient kernels that run concurrently on the executor's side stream.
-static int stream_grid(size_t n4) {
-    const size_t cap = (size_t)g_osi_tuning.bn_grid;
+static int stream_grid(size_t n4, bool backward = false) {
+    const size_t cap = (size_t)(backward ? g_osi_tuning.bn_grid_bwd : g_osi_tuning.bn_grid);
     size_t g = (n4 + NT - 1) / NT;
     return (int)(g > cap ? cap : g);
 }
@@ -678,7 +678,7 @@ static int bn_backward_impl(const float* dout, const void* msk, int mode, const 
     OSI_LAUNCH_CHECK();
     if (!dy) return OSI_OK;     // reductions only (dgamma, dbeta): the caller assembles the consumer's gradient another way
     const size_t n4 = (size_t)M * C / 4;
-    const int grid = stream_grid(n4), c4n = C / 4;
+    const int grid = stream_grid(n4, true), c4n = C / 4;
     auto D = (const f32x4*)dout; auto Y = (const f32x4*)y;
     auto MU = (const f32x4*)mean; auto IS = (const f32x4*)invstd; auto G = (const f32x4*)gamma;
     auto C1 = (const f32x4*)c1; auto C2 = (const f32x4*)c2;
@@ -726,7 +726,7 @@ int osi_bn_backward_fused(const float* g, const float* y, const float* mean, con
     float* c2 = c1 + C;
     if (int e = bwd_reduce_partials(psum_g, psum_gx, P, M, C, gb, gg, S, Pc, dgamma, dbeta, c1, c2, st)) return e;
     const size_t n4 = (size_t)M * C / 4;
-    hipLaunchKernelGGL((k_bn_bwd_apply<0, false>), dim3(stream_grid(n4)), dim3(NT), 0, st, (const f32x4*)g, (const void*)nullptr,
+    hipLaunchKernelGGL((k_bn_bwd_apply<0, false>), dim3(stream_grid(n4, true)), dim3(NT), 0, st, (const f32x4*)g, (const void*)nullptr,
                        (const f32x4*)y, (const f32x4*)mean, (const f32x4*)invstd, (const f32x4*)gamma, (const f32x4*)c1,
                        (const f32x4*)c2, (f32x4*)dy, (f32x4*)nullptr, n4, C / 4, PoolSrc{});
     OSI_LAUNCH_CHECK();

@@ -38,6 +38,7 @@ struct OsiTuning {
     int stem_direct;    // 1 = the stem convolution runs its direct form (k_stem_fwd_direct) where the geometry allows, 0 = implicit GEMM
     int tail_gain;      // balanced remainder: least modelled gain of a launch, in percent, for its ragged round to be split
     int tail_qmax;      // ... and most full rounds a launch may have
+    int bn_grid_bwd;    // grid cap of the BatchNorm BACKWARD apply kernels (they run beside the weight gradients)
     int bn_wide_p;      // BatchNorm finalisation (forward statistics and backward sums): ONE 1024-thread launch up to this many partials
 };
 extern OsiTuning g_osi_tuning;
