@@ -66,6 +66,7 @@ struct osi_resnet50 {
     int Hs, Ws, Hp, Wp;              // stem conv output, maxpool output
     size_t x4, wpack, gpack, a_pool, pool_idx, pooled, feat, logits_ws;
     size_t bn_ws, bn_ws2, bn_ws_bytes, wg_ws, wg_ws_bytes, dg_ws, dg_ws_bytes;   // bn_ws2: BatchNorm scratch of the side-stream branch
+    size_t stem_ws = 0, stem_ws_bytes = 0;
     static constexpr int NSCR = 12;   // scratch activations-gradient buffers (each = largest activation)
     size_t scratch[NSCR], scratch_floats;
     size_t dfeat, dpooled;
@@ -153,6 +154,7 @@ struct osi_resnet50 {
     const float* x4_cur = nullptr;   // input of the step in flight (forward sets it, the stem weight gradient reads it)
     bool stem_pool_stats = true;     // option "stem_pool_stats": bn1's backward reductions come out of layer1.0.conv1's dgrad epilogue
     bool ds_sparse = true;           // option "ds_sparse": stride-2 shortcut gradients write / are read at the even-even pixels only
+    bool stem_wgrad_main = true;     // option "stem_wgrad_main": the fused stem weight gradient runs on the main stream (own workspace)
     int stem_stats_P = 0;            // > 0: bn1's backward partial sums wait in dg_ws (left by the pool-mode epilogue of layer1.0.conv1's dgrad)
     bool stem_fused = true;          // option "stem_fused": conv1's weight gradient builds dY in its operand loader (osi_stem_wgrad_fused)
                                      // behind the BatchNorm reductions: no 112x112x64 gradient tensor, no apply pass (step -0.15 ms)
@@ -286,6 +288,9 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
     }
     n->bn_ws_bytes = bnws; n->bn_ws = n->ws_alloc(bnws / 4 + 4); n->bn_ws2 = n->ws_alloc(bnws / 4 + 4);
     n->wg_ws_bytes = wgws; n->wg_ws = n->ws_alloc(wgws / 4 + 4);
+    // the fused stem weight gradient has its own slab: it may run on the main stream while the side stream still owns wg_ws
+    n->stem_ws_bytes = osi_stem_wgrad_fused_workspace(&n->convs[0].d);
+    n->stem_ws = n->stem_ws_bytes ? n->ws_alloc(n->stem_ws_bytes / 4 + 4) : n->wg_ws;
     n->dg_ws_bytes = dgws; n->dg_ws = n->ws_alloc(dgws / 4 + 4);
     n->scratch_floats = maxact;
     for (int i = 0; i < osi_resnet50::NSCR; ++i) n->scratch[i] = n->ws_alloc(maxact);
@@ -821,7 +826,9 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
                                                     n->bn_ws_bytes, st));
                 }
                 OSI_TRY(n->mark(OSI_PROF_BN_BWD, st));
-                const bool async = n->async_wgrad();
+                // the stem's weight gradient is the last kernel of the step; on the MAIN stream it runs beside the side stream's
+                // backlog (layer1's weight gradients) instead of behind it
+                const bool async = n->async_wgrad() && !n->stem_wgrad_main;
                 hipStream_t gs = st;
                 if (async) {
                     if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
@@ -829,7 +836,8 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
                     gs = n->side;
                 }
                 OSI_TRY(osi_stem_wgrad_fused(&c0.d, S(go), ws + n->pool_idx, ws + c0.y, x4c, params + b0.g_off, ws + b0.mean, ws + b0.invstd,
-                                             grads + b0.g_off, grads + b0.b_off, grads + c0.w_off, ws + n->wg_ws, n->wg_ws_bytes, gs));
+                                             grads + b0.g_off, grads + b0.b_off, grads + c0.w_off, ws + n->stem_ws,
+                                             n->stem_ws_bytes ? n->stem_ws_bytes : n->wg_ws_bytes, gs));
                 if (async) {
                     if (hipEventRecord(n->buf_ev[go], n->side) != hipSuccess) return OSI_ERR_LAUNCH;
                     n->buf_pending[go] = true;
@@ -961,6 +969,7 @@ int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
     else if (!strcmp(name, "stem_fused")) n->stem_fused = value != 0;
     else if (!strcmp(name, "stem_pool_stats")) n->stem_pool_stats = value != 0;
     else if (!strcmp(name, "ds_sparse")) n->ds_sparse = value != 0;
+    else if (!strcmp(name, "stem_wgrad_main")) n->stem_wgrad_main = value != 0;
     else if (!strcmp(name, "side_priority_normal")) {
         if (n->side) return OSI_ERR_STATE;   // the side stream already exists with the other priority
         n->side_prio_normal = value != 0;
