@@ -1873,7 +1873,8 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
     p.w_bytes = (int)((size_t)d->Cout * p.Ktot * 4);
     // Measured (profiles/conv_layers_r01.txt and the full step): with buffer loads the 64x64 single-buffered tile wins or ties
     // on every ResNet-50 shape (the dgrad class went 12.1 -> 11.0 ms per step against the 64x128 rule used before).
-    if (tile == OSI_TILE_AUTO) tile = (g_osi_tuning.dgrad_wide && d->Cin % 128 == 0) ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
+    const bool even_addend = f && f->addend_stride == 2;     // built for the 64x64 epilogue only: AUTO never picks the wide tile for it
+    if (tile == OSI_TILE_AUTO) tile = (g_osi_tuning.dgrad_wide && d->Cin % 128 == 0 && !even_addend) ? OSI_TILE_64x128_S1 : OSI_TILE_64x64_S1;
     if (f) {
         OSI_REQUIRE(f->relu_mask || f->scale0 || !f->partials || f->pool_idx);
         if (f->pool_idx) {   // pool mode: stride-1 conv behind the stem's max-pool, reductions only (no gate on dx), one consumer
@@ -1885,7 +1886,7 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
         OSI_REQUIRE(!f->scale0 || (!f->relu_mask && f->shift0 && f->y0));   // one gate source: the bitmask, or y0 * scale0 + shift0 > 0
         OSI_REQUIRE(f->addend_stride >= 0 && f->addend_stride <= 2);
         if (f->addend_stride == 2) {   // sparse addend: stride-1 convolution, 64x64 tiles, an addend, no pool mode
-            OSI_REQUIRE(addend && d->stride == 1 && !f->pool_idx && (tile == OSI_TILE_AUTO || tile == OSI_TILE_64x64_S1) && !g_osi_tuning.dgrad_wide);
+            OSI_REQUIRE(addend && d->stride == 1 && !f->pool_idx && tile == OSI_TILE_64x64_S1);
             p.eadd_even = 1;
         }
         p.ebits = (const unsigned long long*)f->relu_mask;
