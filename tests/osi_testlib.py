@@ -76,3 +76,11 @@ def hip_gates(model):
         if am is not None:
             pool_idx = am.cpu().long()
     return {"relu": relu, "pool_idx": pool_idx}
+
+
+class Fusion(ctypes.Structure):
+    """osi_dgrad_fusion of include/osi.h (ABI 4)."""
+    _fields_ = [("relu_mask", ctypes.c_void_p), ("y0", ctypes.c_void_p), ("mean0", ctypes.c_void_p), ("invstd0", ctypes.c_void_p),
+                ("y1", ctypes.c_void_p), ("mean1", ctypes.c_void_p), ("invstd1", ctypes.c_void_p), ("partials", ctypes.c_void_p),
+                ("partials_bytes", ctypes.c_size_t), ("scale0", ctypes.c_void_p), ("shift0", ctypes.c_void_p),
+                ("pool_idx", ctypes.c_void_p), ("pool_H", ctypes.c_int), ("pool_W", ctypes.c_int), ("addend_stride", ctypes.c_int)]

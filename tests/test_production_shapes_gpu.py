@@ -1,0 +1,381 @@
+"""Oracle parity on the PRODUCTION launch plans: every convolution shape of ResNet-50 at 224 x 224 at the
+benchmarked batch (B = 128; the layer3 / layer4 shapes also at B = 256, Protocol 3), called through the C ABI in exactly the
+FORMS the executor issues (csrc/resnet50_exec.hip) with AUTO tiles and default tuning — i.e. with the tile rule, the K-split tails
+on a 256-CU plan, the 2048-workgroup split-K budget, the XCD slot mapping and byte offsets of the real step — against torch-CPU
+fp64 (`F.conv2d`, `conv2d_input`, `conv2d_weight`: the arithmetic the reference runs under openset_imagenet/model.py:37 and, for
+the backward, train.py:138), under the per-kernel bound of tests/test_kernels_gpu.py: |err| <= (2e-6 + 6e-8 sqrt(K)) max|ref|.
+
+  forward          osi_conv_fwd_bnstats (conv1 of a bottleneck, projection shortcut, stem) / osi_conv_fwd_act (conv2, conv3),
+                   + the BatchNorm partials of the epilogue, merged here in fp64 AND finished by osi_bn_finalize_stats
+  input gradient   osi_conv_dgrad_fused "in-block" (gate recomputed from the pre-BN tensor + one consumer's sums), "block input"
+                   (addend dense / at the even pixels only / in place, stored bitmask, one or two consumers), pool mode
+                   (layer1.0.conv1), osi_conv_dgrad plain / sparse (projection shortcuts)
+  weight gradient  osi_conv_wgrad / osi_conv_wgrad_act (per-tap kernel, all-taps 3x3 stride 1 and 2), osi_stem_wgrad_direct
+
+and the whole network in train mode at B = 128, 224 x 224, C = 30 (Protocol 2): max |logit - fp64 oracle| <= 1e-4 — the
+north-star sentence literally — plus features and the running-statistics update.
+"""
+import ctypes
+import math
+import time
+import zlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan():
+    """The (form, shape) pairs the executor issues, unique, in network order. Shape = (Cin, Cout, k, stride, H_in)."""
+    from oracle import resnet50_oracle as R
+    fw, dg, wg = {}, {}, {}
+    H, inpl, prev_ds = 56, 64, False
+    for s, (planes, blocks, stride) in enumerate(R.STAGES):
+        for b in range(blocks):
+            st = stride if b == 0 else 1
+            Ho = H // st
+            c1, c2, c3 = (inpl, planes, 1, 1, H), (planes, planes, 3, st, H), (planes, planes * 4, 1, 1, Ho)
+            for form, c in (("plain", c1), ("act", c2), ("act", c3)):
+                fw[(form,) + c] = s
+                wg[(form,) + c] = s
+            dg[("inblock",) + c3] = s
+            dg[("inblock",) + c2] = s
+            if s == 0 and b == 0:
+                dg[("pool",) + c1] = s
+            else:   # (two consumers: the block before has a projection shortcut; addend sparse + in place: this block has a stride-2 one)
+                dg[("blockin", prev_ds, b == 0 and st == 2) + c1] = s
+            if b == 0:
+                ds = (inpl, planes * 4, 1, st, H)
+                fw[("plain",) + ds] = s
+                wg[("plain",) + ds] = s
+                dg[("plain", st == 2) + ds] = s
+            prev_ds = b == 0
+            inpl, H = planes * 4, Ho
+    return fw, dg, wg
+
+
+FW, DG, WG = _plan()
+
+
+def _cases(table):
+    out = []
+    for key, stage in table.items():
+        out.append(pytest.param(key, 128, id="-".join(str(int(v) if isinstance(v, bool) else v) for v in key) + "-b128"))
+        if stage >= 2:
+            out.append(pytest.param(key, 256, id="-".join(str(int(v) if isinstance(v, bool) else v) for v in key) + "-b256"))
+    return out
+
+
+def _bound(K, ref):
+    return (2e-6 + 6e-8 * math.sqrt(K)) * float(ref.abs().max()) + 1e-6
+
+
+def _gen(cuda, *seed):
+    return torch.Generator(device=cuda).manual_seed(zlib.crc32(repr(seed).encode()))
+
+
+def _cpu64(t):
+    return t.detach().cpu().double()
+
+
+def _stats64(v):
+    """fp64 column mean and centred sum of squares of a [M][C] matrix."""
+    m = v.mean(0)
+    return m, ((v - m) ** 2).sum(0)
+
+
+def _check_partials_and_finalize(L, N, T, cuda, ps, nb, P, rows, M, C, ref_rows, gen):
+    """The epilogue's per-row-tile (mean, M2) partials merged in fp64 against the fp64 columns, then the library's own merge
+    (osi_bn_finalize_stats: wide single launch or two levels, chosen by P) against the same."""
+    scale = float(ref_rows.abs().max())
+    rmean, rM2 = _stats64(ref_rows)
+    pm, pq = _cpu64(ps[:P * C]).view(P, C), _cpu64(ps[P * C:2 * P * C]).view(P, C)
+    cnt = torch.full((P, 1), float(rows), dtype=torch.float64)
+    cnt[-1] = M - (P - 1) * rows
+    mean = (pm * cnt).sum(0) / M
+    M2 = pq.sum(0) + (cnt * (pm - mean) ** 2).sum(0)
+    assert float((mean - rmean).abs().max()) <= 2e-6 * scale + 1e-6
+    assert float(((M2 - rM2).abs() / rM2).max()) <= 1e-4
+    gamma = torch.rand(C, device=cuda, generator=gen) + 0.5
+    beta = torch.randn(C, device=cuda, generator=gen) * 0.3
+    rm0, rv0 = torch.randn(C, device=cuda, generator=gen) * 0.1, torch.rand(C, device=cuda, generator=gen) + 0.5
+    rm, rv = rm0.clone(), rv0.clone()
+    o = [torch.empty(C, device=cuda) for _ in range(4)]
+    N.check(L.osi_bn_finalize_stats(N.ptr(ps), nb, P, rows, M, C, N.ptr(gamma), N.ptr(beta), 1e-5, 0.1, N.ptr(rm), N.ptr(rv),
+                                    *[N.ptr(t) for t in o], T.S()), "osi_bn_finalize_stats")
+    var = rM2 / M
+    inv = 1 / torch.sqrt(var + 1e-5)
+    assert float((_cpu64(o[0]) - rmean).abs().max()) <= 2e-6 * scale + 1e-6
+    assert float((_cpu64(o[1]) / inv - 1).abs().max()) <= 2e-5
+    sc64 = _cpu64(gamma) * inv
+    assert float((_cpu64(o[2]) / sc64 - 1).abs().max()) <= 2e-5
+    assert float((_cpu64(o[3]) - (_cpu64(beta) - rmean * sc64)).abs().max()) <= 2e-5 * (1 + scale * float(sc64.abs().max()))
+    assert float((_cpu64(rm) - (0.9 * _cpu64(rm0) + 0.1 * rmean)).abs().max()) <= 1e-6 * (1 + scale)
+    assert float((_cpu64(rv) / (0.9 * _cpu64(rv0) + 0.1 * rM2 / (M - 1)) - 1).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("key,B", _cases(FW))
+def test_forward_forms_at_production_batch(cuda, key, B):
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    form, Cin, Cout, k, st, H = key
+    pad = 1 if k == 3 else 0
+    g = _gen(cuda, "fwd", key, B)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, k, st, pad)
+    x = torch.randn(B, H, H, Cin, device=cuda, generator=g) * 1.2 + 0.3
+    w = torch.randn(Cout, k, k, Cin, device=cuda, generator=g) / math.sqrt(Cin * k * k)
+    a64 = _cpu64(x)
+    sc = sh = None
+    if form == "act":
+        sc, sh = torch.rand(Cin, device=cuda, generator=g) + 0.5, torch.randn(Cin, device=cuda, generator=g) * 0.5
+        a64 = torch.relu(a64 * _cpu64(sc) + _cpu64(sh))
+    ref = F.conv2d(T.nchw(a64), T.oihw(_cpu64(w)), None, st, pad).permute(0, 2, 3, 1).contiguous()
+    nb = L.osi_conv_fwd_bnstats_workspace(ctypes.byref(d))
+    ps = torch.full((nb // 4,), float("nan"), device=cuda)
+    y = torch.full((B, d.Ho, d.Wo, Cout), float("nan"), device=cuda)
+    P, rows = ctypes.c_int(), ctypes.c_int()
+    if form == "act":
+        N.check(L.osi_conv_fwd_act(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(w), N.ptr(y), 0, N.ptr(ps), nb, ctypes.byref(P),
+                                   ctypes.byref(rows), T.S()), "osi_conv_fwd_act")
+    else:
+        N.check(L.osi_conv_fwd_bnstats(ctypes.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), 0, N.ptr(ps), nb, ctypes.byref(P), ctypes.byref(rows),
+                                       T.S()), "osi_conv_fwd_bnstats")
+    M = B * d.Ho * d.Wo
+    err = float((_cpu64(y) - ref).abs().max())
+    assert err <= _bound(Cin * k * k, ref), f"{key} B={B}: {err:.3e} > {_bound(Cin * k * k, ref):.3e}"
+    assert (P.value, rows.value) == ((M + 63) // 64, 64)
+    _check_partials_and_finalize(L, N, T, cuda, ps, nb, P.value, rows.value, M, Cout, ref.view(M, Cout), g)
+
+
+@pytest.mark.parametrize("B", [128])
+def test_stem_forward_and_weight_gradient_at_production_batch(cuda, B):
+    """conv1 (7x7 / 2, 3 -> 64) at 224 x 224 through the direct kernels the executor uses: forward + BatchNorm partials per 8 x 16
+    output tile, weight gradient in the parameter layout."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = _gen(cuda, "stem", B)
+    H = 224
+    img = torch.rand(B, 3, H, H, device=cuda, generator=g)
+    w = torch.randn(64, 3, 7, 7, device=cuda, generator=g) * math.sqrt(2.0 / (64 * 49))
+    x4 = torch.empty(B, H, H, 4, device=cuda)
+    N.check(L.osi_nchw3_to_nhwc4(N.ptr(img), N.ptr(x4), B, H, H, T.S()))
+    wk = T.krsc(w)
+    wp = torch.empty(64, 224, device=cuda)
+    N.check(L.osi_stem_weight_pack(N.ptr(wk), N.ptr(wp), 64, T.S()))
+    d = N.ConvDesc.make(B, H, H, 4, 64, 7, 2, 3)
+    nb = L.osi_conv_fwd_bnstats_workspace(ctypes.byref(d))
+    ps = torch.full((nb // 4,), float("nan"), device=cuda)
+    y = torch.full((B, d.Ho, d.Wo, 64), float("nan"), device=cuda)
+    P, rows = ctypes.c_int(), ctypes.c_int()
+    N.check(L.osi_conv_fwd_bnstats(ctypes.byref(d), N.ptr(x4), N.ptr(wp), N.ptr(y), 0, N.ptr(ps), nb, ctypes.byref(P), ctypes.byref(rows), T.S()))
+    ref = F.conv2d(_cpu64(img), _cpu64(w), None, 2, 3).permute(0, 2, 3, 1).contiguous()
+    M = B * d.Ho * d.Wo
+    assert float((_cpu64(y) - ref).abs().max()) <= _bound(147, ref)
+    assert rows.value == 128 and P.value == M // 128, "the direct stem kernel ran (one partial per 8 x 16 tile)"
+    # the direct kernel's partial of tile t covers an 8 x 16 pixel patch, not rows [128 t, 128 t + 128): merge them all
+    pm, pq = _cpu64(ps[:P.value * 64]).view(-1, 64), _cpu64(ps[P.value * 64:2 * P.value * 64]).view(-1, 64)
+    mean = pm.mean(0)
+    M2 = pq.sum(0) + (128.0 * (pm - mean) ** 2).sum(0)
+    rmean, rM2 = _stats64(ref.view(M, 64))
+    assert float((mean - rmean).abs().max()) <= 2e-6 * float(ref.abs().max()) and float((M2 / rM2 - 1).abs().max()) <= 1e-4
+    # weight gradient, direct form
+    dy = torch.randn(B, d.Ho, d.Wo, 64, device=cuda, generator=g)
+    wsb = L.osi_stem_wgrad_direct_workspace(ctypes.byref(d))
+    assert wsb > 0
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    dw = torch.full((64, 7, 7, 3), float("nan"), device=cuda)
+    N.check(L.osi_stem_wgrad_direct(ctypes.byref(d), N.ptr(dy), N.ptr(x4), N.ptr(dw), N.ptr(ws), wsb, T.S()), "osi_stem_wgrad_direct")
+    rdw = torch.nn.grad.conv2d_weight(_cpu64(img), (64, 3, 7, 7), T.nchw(_cpu64(dy)), 2, 3)
+    assert float((_cpu64(T.oihw(dw)) - rdw).abs().max()) <= _bound(M, rdw)
+
+
+@pytest.mark.parametrize("key,B", _cases(WG))
+def test_weight_gradient_forms_at_production_batch(cuda, key, B):
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    form, Cin, Cout, k, st, H = key
+    pad = 1 if k == 3 else 0
+    g = _gen(cuda, "wgrad", key, B)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, k, st, pad)
+    x = torch.randn(B, H, H, Cin, device=cuda, generator=g) * 1.2 + 0.3
+    dy = torch.randn(B, d.Ho, d.Wo, Cout, device=cuda, generator=g)
+    a64 = _cpu64(x)
+    nb = L.osi_conv_wgrad_workspace(ctypes.byref(d))
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=cuda)
+    dw = torch.full((Cout, k, k, Cin), float("nan"), device=cuda)
+    if form == "act":
+        sc, sh = torch.rand(Cin, device=cuda, generator=g) + 0.5, torch.randn(Cin, device=cuda, generator=g) * 0.5
+        a64 = torch.relu(a64 * _cpu64(sc) + _cpu64(sh))
+        N.check(L.osi_conv_wgrad_act(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(dw), N.ptr(ws), nb, T.S()), "osi_conv_wgrad_act")
+    else:
+        N.check(L.osi_conv_wgrad(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(dw), N.ptr(ws), nb, T.S()), "osi_conv_wgrad")
+    ref = torch.nn.grad.conv2d_weight(T.nchw(a64), (Cout, Cin, k, k), T.nchw(_cpu64(dy)), st, pad).permute(0, 2, 3, 1)
+    err = float((_cpu64(dw) - ref).abs().max())
+    Kp = B * d.Ho * d.Wo
+    assert err <= _bound(Kp, ref), f"{key} B={B}: {err:.3e} > {_bound(Kp, ref):.3e}"
+
+
+def _xhat_sums(g64, y, mean, invstd):
+    """fp64 column sums of g and g * xhat with the fp32 mean / invstd the kernel was given; also the column L1 of g * xhat."""
+    xh = (_cpu64(y) - _cpu64(mean)) * _cpu64(invstd)
+    return g64.sum(0), (g64 * xh).sum(0), (g64 * xh).abs().sum(0)
+
+
+def _col_stats(y):
+    v = y.double()
+    return v.mean(0).float(), (1 / torch.sqrt(v.var(0, unbiased=False) + 1e-5)).float()
+
+
+@pytest.mark.parametrize("key,B", _cases(DG))
+def test_input_gradient_forms_at_production_batch(cuda, key, B):
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    form = key[0]
+    Cin, Cout, k, st, H = key[-5:]
+    pad = 1 if k == 3 else 0
+    g = _gen(cuda, "dgrad", key, B)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, k, st, pad)
+    M = B * H * H
+    dy = torch.randn(B, d.Ho, d.Wo, Cout, device=cuda, generator=g)
+    w = torch.randn(Cout, k, k, Cin, device=cuda, generator=g) / math.sqrt(Cout * k * k)
+    acc = torch.nn.grad.conv2d_input((B, Cin, H, H), T.oihw(_cpu64(w)), T.nchw(_cpu64(dy)), st, pad).permute(0, 2, 3, 1).contiguous()
+    K = Cout * k * k
+
+    if form == "plain":           # projection shortcut: dense, or only the even-even pixels of a stride-2 1x1 (the rest untouched)
+        sparse = key[1]
+        dx = torch.full((B, H, H, Cin), float("nan"), device=cuda)
+        N.check(L.osi_conv_dgrad(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(dx), 2 if sparse else 0, 0, T.S()), "osi_conv_dgrad")
+        got = _cpu64(dx)
+        if sparse:
+            assert bool(torch.isnan(got[:, 1::2]).all()) and bool(torch.isnan(got[:, :, 1::2]).all()), "pixels no tap reaches stay untouched"
+            got, acc = got[:, ::2, ::2], acc[:, ::2, ::2]
+        assert float((got - acc).abs().max()) <= _bound(K, acc)
+        return
+
+    pb = L.osi_conv_dgrad_fused_workspace(ctypes.byref(d))
+    parts = torch.full((pb // 4,), float("nan"), device=cuda)
+    P = ctypes.c_int()
+    if form == "inblock":
+        # the producer's activation relu(bn(y0)) was never stored: gate = fma(y0, scale0, shift0) > 0, pre-activations kept 1e-3
+        # away from zero so that fp32 / fp64 agree on every decision
+        sc, sh = torch.rand(Cin, device=cuda, generator=g) + 0.5, torch.randn(Cin, device=cuda, generator=g) * 0.5
+        pre = torch.randn(M, Cin, device=cuda, generator=g)
+        pre = torch.where(pre >= 0, pre.clamp_min(1e-3), pre.clamp_max(-1e-3))
+        y0 = ((pre.double() - sh.double()) / sc.double()).float()
+        gate = _cpu64(pre > 0).view(B, H, H, Cin)
+        mean0, inv0 = _col_stats(y0)
+        f = T.Fusion(None, y0.data_ptr(), mean0.data_ptr(), inv0.data_ptr(), None, None, None, parts.data_ptr(), pb, sc.data_ptr(), sh.data_ptr())
+        dx = torch.full((B, H, H, Cin), float("nan"), device=cuda)
+        N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(dx), None, ctypes.byref(f), 0, ctypes.byref(P), T.S()), "dgrad in-block")
+        ref = acc * gate
+        consumers = [(y0, mean0, inv0)]
+    elif form == "blockin":
+        two, sparse = key[1], key[2]
+        pre = torch.randn(M, Cin, device=cuda, generator=g)
+        ones, zeros = torch.ones(Cin, device=cuda), torch.zeros(Cin, device=cuda)
+        out = torch.empty(M, Cin, device=cuda)
+        mask = torch.zeros(L.osi_bn_relu_mask_bytes(M, Cin), dtype=torch.uint8, device=cuda)
+        N.check(L.osi_bn_apply_relu_mask(N.ptr(pre), None, N.ptr(ones), N.ptr(zeros), N.ptr(out), N.ptr(mask), M, Cin, T.S()))
+        gate = _cpu64(pre > 0).view(B, H, H, Cin)
+        del out
+        ys = [torch.randn(M, Cin, device=cuda, generator=g) * 2 + 0.5 for _ in range(2 if two else 1)]
+        consumers = [(yy,) + _col_stats(yy) for yy in ys]
+        addend = torch.randn(B, H, H, Cin, device=cuda, generator=g)
+        a64 = _cpu64(addend)
+        if sparse:      # a stride-2 shortcut wrote the even-even pixels only; everything else in the buffer is stale: poison it
+            keep = torch.zeros(1, H, H, 1, dtype=torch.bool, device=cuda)
+            keep[:, ::2, ::2] = True
+            addend = torch.where(keep, addend, torch.full_like(addend, float("nan")))
+            a64 = a64 * _cpu64(keep)
+            dx = addend                                     # completed in place, as the executor does for a block with a projection
+        else:
+            dx = torch.full((B, H, H, Cin), float("nan"), device=cuda)
+        f = T.Fusion(mask.data_ptr(), ys[0].data_ptr(), consumers[0][1].data_ptr(), consumers[0][2].data_ptr(),
+                     ys[1].data_ptr() if two else None, consumers[1][1].data_ptr() if two else None, consumers[1][2].data_ptr() if two else None,
+                     parts.data_ptr(), pb, None, None, None, 0, 0, 2 if sparse else 1)
+        N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(dx), N.ptr(addend), ctypes.byref(f), 0, ctypes.byref(P), T.S()), "dgrad block input")
+        ref = (acc + a64) * gate
+    else:               # pool mode: layer1.0.conv1, whose input is the stem's bn1 -> ReLU -> max-pool output
+        Hs = 2 * H
+        ystem = torch.randn(B, Hs, Hs, Cin, device=cuda, generator=g) * 1.5 + 0.2
+        bsc, bsh = torch.rand(Cin, device=cuda, generator=g) + 0.5, torch.randn(Cin, device=cuda, generator=g) * 0.5
+        pooled = torch.empty(B, H, H, Cin, device=cuda)
+        idx = torch.zeros(B * H * H * Cin, dtype=torch.uint8, device=cuda)
+        N.check(L.osi_bn_relu_maxpool_fwd(N.ptr(ystem), N.ptr(bsc), N.ptr(bsh), N.ptr(pooled), N.ptr(idx), B, Hs, Hs, Cin, T.S()))
+        del pooled
+        mean0, inv0 = _col_stats(ystem.view(-1, Cin))
+        dx = torch.randn(B, H, H, Cin, device=cuda, generator=g)          # the shortcut branch's gradient, completed in place
+        a64 = _cpu64(dx)
+        f = T.Fusion(None, ystem.data_ptr(), mean0.data_ptr(), inv0.data_ptr(), None, None, None, parts.data_ptr(), pb, None, None,
+                     idx.data_ptr(), Hs, Hs, 1)
+        N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(dx), N.ptr(dx), ctypes.byref(f), 0, ctypes.byref(P), T.S()), "dgrad pool mode")
+        ref = acc + a64
+        # reductions: the pooled element's gradient lands on its window's arg-max pixel, gated by the window's ReLU (bit 7)
+        by = idx.view(B, H, H, Cin).cpu().long()
+        tap = by & 0x7F
+        ho = torch.arange(H).view(1, H, 1, 1)
+        wo = torch.arange(H).view(1, 1, H, 1)
+        flat = ((2 * ho - 1 + tap // 3) * Hs + (2 * wo - 1 + tap % 3)).clamp_(0, Hs * Hs - 1)   # closed windows carry no gradient
+        yarg = _cpu64(ystem).view(B, Hs * Hs, Cin).gather(1, flat.view(B, H * H, Cin)).view(B, H, H, Cin)
+        gv = ref * (by >> 7).double()
+        xh = (yarg - _cpu64(mean0)) * _cpu64(inv0)
+        want = [(gv.view(M, Cin).sum(0), (gv * xh).view(M, Cin).sum(0), (gv * xh).abs().view(M, Cin).sum(0))]
+        consumers = None
+
+    got = _cpu64(dx)
+    err = float((got - ref).abs().max())
+    assert err <= _bound(K, ref), f"{key} B={B}: {err:.3e} > {_bound(K, ref):.3e}"
+    if form != "pool":
+        assert bool((got[gate == 0] == 0).all()), "exact zeros behind a closed gate"
+        want = [_xhat_sums(ref.view(M, Cin), *c) for c in consumers]
+    Pn = P.value
+    p = _cpu64(parts[:3 * Pn * Cin]).view(3, Pn, Cin)
+    sg = p[0].sum(0)
+    l1g = ref.view(M, Cin).abs().sum(0) if form != "pool" else gv.view(M, Cin).abs().sum(0)
+    assert float(((sg - want[0][0]).abs() / (l1g + 1e-3)).max()) <= 1e-5, "sum g"
+    for i, (_, sgx, l1) in enumerate(want):
+        e = float(((p[1 + i].sum(0) - sgx).abs() / (l1 + 1e-3)).max())
+        assert e <= 2e-5, f"sum g * xhat{i}: {e:.2e}"
+
+
+@pytest.mark.parametrize("C,B,logit_bias", [(30, 128, False)])
+def test_whole_network_train_forward_at_production_batch(cuda, C, B, logit_bias):
+    """ResNet50.forward (reference model.py:28-39) in train mode on the benchmark's own workload shape: Protocol 2 (C = 30), B = 128,
+    224 x 224. max |logit - fp64 oracle| <= 1e-4 — BASELINE.json's tolerance on BASELINE.json's configuration — plus the features
+    and the BatchNorm running-statistics update (momentum 0.1, unbiased variance) of all 53 layers."""
+    from openset_imagenet import ResNet50
+    from oracle import resnet50_oracle as R
+    gen = torch.Generator().manual_seed(1234)
+    sd = R.randomize_bn(R.init_state(C, C, logit_bias, generator=gen), generator=gen)
+    model = ResNet50(C, C, logit_bias)
+    model.load_state_dict(sd)
+    model = model.to(cuda)
+    x = torch.rand(B, 3, 224, 224, generator=gen)
+    model.train()
+    with torch.no_grad():
+        logits, feats = model(x.to(cuda))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    with torch.no_grad():
+        rl, rf = R.forward(sd64, x.double(), training=True)
+    print(f"fp64 oracle forward at B={B}: {time.time() - t0:.1f} s")
+    e_l = float((logits.cpu().double() - rl).abs().max())
+    e_f = float((feats.cpu().double() - rf).abs().max())
+    print(f"B={B} C={C} 224x224 train forward: max|logit - fp64 oracle| = {e_l:.2e} (|logit| <= {float(rl.abs().max()):.2f}), features {e_f:.2e}")
+    assert e_l <= 1e-4 and e_f <= 1e-4
+    got = model.state_dict()
+    worst = 0.0
+    for k, v in sd64.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            worst = max(worst, float((got[k].cpu().double() - v).abs().max() / (v.abs().max() + 1e-6)))
+        elif k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(v) == 1
+    print(f"running statistics of 53 BatchNorms: worst relative deviation {worst:.2e}")
+    assert worst <= 1e-4
