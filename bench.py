@@ -75,8 +75,22 @@ def _cpu_leg(C, p_neg, loss, steps, B):
     return best, B / best
 
 
-def usable_cpus():
-    """How many CPUs' worth of time this process can get, and every limit that went into it."""
+def cpu_model():
+    """CPU model string of the host (SURVEY.md §8d asks for core count AND model)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def usable_cpus(gpus_used=1, cpus_per_gpu=16):
+    """How many CPUs' worth of time this process can get, and every limit that went into it. `cpus_per_gpu` is the lease policy of
+    the pool (--cpus-per-gpu / OSI_CPUS_PER_GPU, 16 on this one), multiplied by the GPUs THIS RUN uses — not by the devices that
+    happen to be visible."""
     n = os.cpu_count() or 1
     aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else n
     quota = None
@@ -92,22 +106,21 @@ def usable_cpus():
             break
         except (OSError, ValueError, IndexError):
             continue
-    gpus = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    share = 16 * max(1, gpus)
+    share = cpus_per_gpu * max(1, gpus_used)
     return {"threads": max(1, min(n, aff, quota or n, share)), "host_cpu_count": n, "affinity_cpus": aff, "cgroup_cpu_quota": quota,
-            "lease_share_16_per_gpu": share}
+            "cpus_per_gpu": cpus_per_gpu, "gpus_used": gpus_used, "lease_share": share}
 
 
-def cpu_baseline(C, p_neg, steps=5, B=32):
+def cpu_baseline(C, p_neg, steps=5, B=32, gpus_used=1, cpus_per_gpu=16):
     """The CPU oracle (torch-CPU restatement of the reference path) timed on this host's cores, the two legs SURVEY.md §8(d) names:
     the GPU workload's own loss at B = 32 (`value`) and BASELINE.json config 1 (Protocol 1, C = 116, softmax cross-entropy, B = 32)."""
     # SURVEY.md §8(d) says torch.set_num_threads(os.cpu_count()). On a GPU box that is wrong by an order of magnitude: the host has 256
     # logical CPUs but a one-GPU lease owns a share of them (16 per GPU on this pool), and 128-256 compute threads on 16 CPUs' worth of
     # time make every oneDNN primitive crawl (round 2: 10.2 s per step with torch's default 128 threads, against 3.7-5.3 s on 8 cores
     # in the build container; 256 threads did not finish a step in 7 minutes). The thread count is therefore the CPU time this process
-    # can actually get: min(os.cpu_count(), affinity mask, cgroup CPU quota, 16 per visible GPU).
+    # can actually get: min(os.cpu_count(), affinity mask, cgroup CPU quota, --cpus-per-gpu x the GPUs this run uses).
     default_threads = torch.get_num_threads()
-    limits = usable_cpus()
+    limits = usable_cpus(gpus_used, cpus_per_gpu)
     want = limits["threads"]
     torch.set_num_threads(want)
     try:
@@ -116,11 +129,11 @@ def cpu_baseline(C, p_neg, steps=5, B=32):
         used = torch.get_num_threads()
     finally:
         torch.set_num_threads(default_threads)
-    return {"value": round(ips, 3), "unit": "images/sec", "cores": used, "kind": "port",
+    return {"value": round(ips, 3), "unit": "images/sec", "cores": used, "cpu_model": cpu_model(), "kind": "port",
             "threads": {"used": used, "set_num_threads_applied": True, "set_to_os_cpu_count": want == (os.cpu_count() or 0),
                         "torch_default": default_threads, **limits,
-                        "rule": "torch.set_num_threads(min(os.cpu_count(), affinity mask, cgroup CPU quota, 16 per visible GPU)): the CPUs this "
-                                "process can actually get; SURVEY.md §8(d)'s plain os.cpu_count() oversubscribes a one-GPU lease 16x"},
+                        "rule": "torch.set_num_threads(min(os.cpu_count(), affinity mask, cgroup CPU quota, cpus_per_gpu x gpus_used)): the CPUs "
+                                "this process can actually get; SURVEY.md §8(d)'s plain os.cpu_count() oversubscribes a one-GPU lease 16x"},
             "sample": f"best of {steps} timed steps (after 1 warm-up) of batch {B}, same shapes/loss as the GPU workload, best step {best:.2f} s; "
                       f"oracle/resnet50_oracle.py (torch-CPU fp32 restatement; the reference package itself is not importable offline)",
             "config1_protocol1_softmax_b32": {"value": round(ips1, 3), "unit": "images/sec",
@@ -219,6 +232,26 @@ def rccl_proof(model, net, backend, world, local, dev):
             "collective": "all_reduce(AVG) per backward stage on a contiguous slice of the gradient arena, async beside the remaining backward"}
 
 
+def rccl_channels(path):
+    """Channel count of the RCCL communicator from its INIT log ("N coll channels", "Channel 00/N"), plus the environment overrides
+    that would pin it. None when the log does not say."""
+    import re
+    info = {"NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"), "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+            "coll_channels": None, "source": None}
+    try:
+        txt = open(path, errors="replace").read() if path else ""
+    except OSError:
+        txt = ""
+    m = re.findall(r"(\d+) coll channels", txt)
+    if m:
+        info.update(coll_channels=int(m[-1]), source='"N coll channels" line of the NCCL_DEBUG=INFO init log')
+    else:
+        m = re.findall(r"Channel \d+/(\d+)", txt)
+        if m:
+            info.update(coll_channels=int(m[-1]), source='"Channel xx/N" lines of the NCCL_DEBUG=INFO init log')
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,11 +260,15 @@ def main():
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; the median window is reported")
     ap.add_argument("--workload", default="p2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the headline config)")
+    ap.add_argument("--cpus-per-gpu", type=int, default=int(os.environ.get("OSI_CPUS_PER_GPU", "16")),
+                    help="CPU share of one GPU lease on this pool: caps the CPU baseline's thread count (x the GPUs this run uses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumentation of the executor")
     ap.add_argument("--force-dp", action="store_true", help="dev: with one rank, still run the data-parallel step (staged backward + "
                     "RCCL bucket all-reduce on a world-1 communicator) to price the N>1 code path on a one-GPU box")
     args = ap.parse_args()
+    if args.windows < 1 or args.steps < 1 or args.warmup < 0 or args.cpus_per_gpu < 1:
+        ap.error("--windows, --steps and --cpus-per-gpu must be >= 1, --warmup >= 0")
 
     # stdout carries exactly ONE line (the JSON); anything libraries print on fd 1 (RCCL's version banner, for one) goes to stderr
     sys.stdout.flush()
@@ -254,9 +291,15 @@ def main():
         local %= max(1, torch.cuda.device_count())
     dev = tools.set_device_gpu(local)
     use_dp = world > 1 or args.force_dp
+    rccl_log = None
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
+        if backend == "nccl" and rank == 0 and "NCCL_DEBUG" not in os.environ:
+            # RCCL has no API for its channel count (= the workgroups a collective keeps resident on this GPU): read it from the
+            # communicator's own INIT log, written to a private file (stdout stays one JSON line)
+            rccl_log = f"/tmp/osi_rccl_init_{os.getpid()}.log"
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=rccl_log)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -307,12 +350,14 @@ def main():
     # Three back-to-back windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and reduced with
     # MAX over the ranks; the MEDIAN window is the reported one (`value`, `ms_per_step`), all three are listed. One 0.7 s window
     # moves by +-1.5 % between identical runs; the median of three resolves ~1 % levers with the same `steps` per window.
-    windows = []
+    windows, own_windows = [], []
     for _ in range(args.windows):
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             last = step()
+        torch.cuda.synchronize()
+        own_windows.append(time.perf_counter() - t0)    # this rank's own finish time (before the barrier): a straggler shows here
         fence()
         w = time.perf_counter() - t0
         if world > 1:
@@ -329,13 +374,36 @@ def main():
         torch.cuda.synchronize()
         comm = net.sync.read_timing()
         net.sync.timing(False)
+        # what every rank saw, gathered over the process group itself: a SCALE record must show a straggler or one rank's exposed
+        # communication, not only the MAX that `value` is computed from
+        mine = {"rank": rank, "own_ms_per_step_windows": [round(w / args.steps * 1e3, 3) for w in own_windows],
+                "exposed_comm_ms": None if comm["exposed_comm_ms"] is None else round(comm["exposed_comm_ms"], 3),
+                "comm_ms_per_step": None if comm["comm_ms_per_step"] is None else round(comm["comm_ms_per_step"], 3)}
+        per_rank = [None] * world
+        if world > 1:
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
+        med = [sorted(r["own_ms_per_step_windows"])[len(r["own_ms_per_step_windows"]) // 2] for r in per_rank]
+        knob = ctypes.c_int()
+        plan = {}
+        for name in ("tail_cus", "dp_reserved_cus", "tail_split"):
+            N.check(N.lib().osi_get_tuning(name.encode(), ctypes.byref(knob)))
+            plan[name] = knob.value
+        hw = torch.cuda.get_device_properties(dev).multi_processor_count
+        plan.update(hw_cus=hw, tail_plan_cus_in_effect=plan["tail_cus"] or max(8, hw - plan["dp_reserved_cus"]),
+                    note="CU count the balanced-remainder plan of the forward / input-gradient launches assumes; dp_reserved_cus (OSI_DP_RESERVED_CUS) "
+                         "leaves wave slots to RCCL's resident channel workgroups (one 256-thread workgroup per channel = 1/8 of a CU's slots)")
+        rccl.update(per_rank=per_rank, per_rank_ms_per_step={"min": min(med), "median": sorted(med)[len(med) // 2], "max": max(med)},
+                    launch_plan=plan, channels=rccl_channels(rccl_log) if backend == "nccl" else None)
         rccl.update(comm_ms_per_step=None if comm["comm_ms_per_step"] is None else round(comm["comm_ms_per_step"], 3),
                     per_bucket_comm_ms=None if comm["per_bucket_ms"] is None else [round(v, 3) for v in comm["per_bucket_ms"]],
                     exposed_comm_ms=None if comm["exposed_comm_ms"] is None else round(comm["exposed_comm_ms"], 3),
                     comm_steps=comm["steps"],
-                    comm_how="instrumented steps after the timed windows: each bucket's all_reduce issued from a dedicated stream between two "
-                             "HIP events (its duration incl. the wait for the bucket's producer); exposed = compute-stream wait in finish() "
-                             "after the whole backward was enqueued")
+                    comm_how="instrumented steps after the timed windows: each bucket's all_reduce is issued from the communication stream "
+                             "between two HIP events, the first recorded behind the hand-off (osi_resnet50_grads_ready: the stage's main- "
+                             "and side-stream producers), so a bucket's figure is the collective's own duration; exposed = how long the "
+                             "compute stream waited for the communication stream in finish(), after the whole backward was enqueued")
     # Roofline leg: the same step, right after the timed region, with one HIP event after every executor op on the launch
     # stream. The instrumented mode keeps every kernel on that one stream (weight gradients are NOT moved to the side stream),
     # so each class's duration is its own; the headline `value` above comes from the un-instrumented, overlapped steps.
@@ -395,7 +463,7 @@ def main():
         if rccl is not None:
             out["rccl"] = rccl
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(C, wl["p_neg"])
+            out["cpu_baseline"] = cpu_baseline(C, wl["p_neg"], gpus_used=world, cpus_per_gpu=args.cpus_per_gpu)
             out["parity"] = parity
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -34,11 +34,32 @@ typedef void* osi_stream_t; /* hipStream_t */
 int osi_abi_version(void);            /* bumped on any signature change */
 const char* osi_build_arch(void);     /* "gfx950" */
 const char* osi_strerror(int code);
-/* Process-wide development knobs (A/B measurements; the defaults are the measured optimum). Launch functions only READ them and
- * never consult the environment. Names: "wgrad_tile" (64 = force 64x64 weight-gradient tiles), "wgrad_blocks" (split-K footprint
- * budget), "wgrad_nst" (LDS stages, 1|2), "wgrad_group" (weight-gradient block-to-XCD mapping, 0|1|2), "wgrad3" (3x3 stride-1 weight gradients on the
- * all-taps kernel, 0|1), "wgrad3_blocks" (its split-K workgroup budget), "fwd_wide" / "dgrad_wide" (force 64x128 tiles, A/B only), "bn_grid" (grid cap of the
- * BatchNorm stream kernels), "bn_single_p" (BatchNorm statistics: one merge launch up to this many row-tile partials), "tail_gain" / "tail_qmax" (balanced remainder: least modelled gain in percent / most full rounds for a launch to be split), "bn_grid_bwd" (the same cap for the backward apply kernels), "bn_wide_p" (one 1024-thread merge launch up to this many partials, forward statistics and backward sums; 0 = always two levels). Unknown name / out-of-range value -> OSI_ERR_ARG. Not meant to be changed while launches are in flight. */
+/* Process-wide development knobs (A/B measurements; every default is the measured optimum). Launch functions only READ them and never
+ * consult the environment. Unknown name or a value outside the knob's range -> OSI_ERR_ARG (nothing is changed). Not to be changed while
+ * launches are in flight; an executor (osi_resnet50_create) sizes its workspace for the values in force at create and refuses to run
+ * (OSI_ERR_STATE) once a plan-relevant one (marked *) differs.
+ *   name             range         default  meaning
+ *   wgrad_tile *     0 | 64        0        64 forces 64x64 weight-gradient tiles; 0 = 128-wide wherever the channel counts allow
+ *   wgrad_blocks *   1 .. 2^20     2048     split-K footprint budget of one weight-gradient launch, in 64x64-workgroup units
+ *   wgrad_nst        1 | 2         1        LDS stages of the per-tap weight-gradient kernel
+ *   wgrad_group *    0 .. 2        2        weight-gradient block -> XCD mapping: 0 plain 2-D grid, 1 the taps of a cell share an XCD, 2 whole K splits do
+ *   wgrad3 *         0 .. 2        2        all-taps 3x3 weight-gradient kernel: 0 never, 1 stride-1 layers, 2 stride-2 layers too
+ *   wgrad3_blocks *  1 .. 2^20     768      workgroups per launch its split-K plan aims for
+ *   fwd_wide         0 | 1         0        A/B: 64x128 forward tiles wherever Cout % 128 == 0
+ *   dgrad_wide       0 | 1         0        A/B: 64x128 input-gradient tiles wherever Cin % 128 == 0
+ *   bn_grid          1 .. 2^20     1024     grid cap of the BatchNorm stream kernels
+ *   bn_grid_bwd      1 .. 2^20     1024     the same for the backward apply kernels
+ *   bn_single_p      1 .. 2^20     128      BatchNorm partials merged by ONE 256-thread launch up to this many row tiles
+ *   bn_wide_p        0 .. 2048     2048     ... by ONE 1024-thread launch up to this many (0 = two levels above bn_single_p)
+ *   tail_split *     0 | 1         1        forward / input-gradient launches split the tiles of their ragged last round along K
+ *   tail_cus *       0 .. 4096     0        CU count the tail plan balances for; 0 = the device's (minus dp_reserved_cus). Affects ONLY that
+ *                                           plan: the stem weight-gradient grid always follows the hardware CU count
+ *   tail_smax *      1 .. 64       8        most K splits a remainder tile is cut into
+ *   tail_mint *      1 .. 4096     16       fewest K tiles (of 32) a split keeps
+ *   tail_gain *      0 .. 100      8        least modelled gain of a launch, in percent, for its ragged round to be split
+ *   tail_qmax *      0 .. 4096     8        most full rounds a launch may have and still be split
+ *   stem_direct *    0 | 1         1        conv1 runs the direct kernels (forward, weight gradient, fused tail) where the geometry allows
+ *   dp_reserved_cus * 0 .. 128     0        data parallel: CUs' worth of wave slots the tail plan leaves to co-resident communication kernels */
 int osi_set_tuning(const char* name, int value);
 int osi_get_tuning(const char* name, int* value);
 
@@ -306,13 +327,21 @@ int osi_resnet50_forward(osi_resnet50_t net, const float* params, float* buffers
 int osi_resnet50_backward(osi_resnet50_t net, const float* params, float* grads, void* workspace, const float* dlogits,
                           const float* dfeatures, int stage_lo, int stage_hi, osi_stream_t stream);
 
+/* Data-parallel hand-off (ABI 5). With option "stage_join" = 0 a staged osi_resnet50_backward call (stage_hi < stages) does NOT make
+ * `stream` wait for the side stream's weight gradients (the last stage always does); instead the caller makes its COMMUNICATION stream
+ * wait for everything the finished stages produced: osi_resnet50_grads_ready(net, main, waiter) records the progress of `main` (the
+ * stream the backward calls were issued on) and of the executor's side stream and makes `waiter` wait for both — `main` itself waits
+ * for nothing and goes on with the next stage while the collective runs (reference intent: config/train.yaml:18,35-39). */
+int osi_resnet50_grads_ready(osi_resnet50_t net, osi_stream_t main_stream, osi_stream_t waiter_stream);
+
 /* Weight gradients on a low-priority side stream, overlapped with dgrad / BatchNorm backward (default on; joined back into
- * `stream` at the end of every backward stage). enable = 0 serialises everything on the caller's stream. */
+ * `stream` at the end of every backward call unless "stage_join" = 0). enable = 0 serialises everything on the caller's stream. */
 int osi_resnet50_set_overlap(osi_resnet50_t net, int enable);
 /* Per-executor switches: "overlap" (= osi_resnet50_set_overlap), "fwd_fork" (projection shortcut of the forward pass on the side
  * stream, default 1), "fwd_recompute" (conv1 of a bottleneck recomputes the previous identity-shortcut block output in its loader and
  * that block's output pass runs beside it on the side stream; default 0: measured no faster), "side_priority_normal" (side stream at default instead of lowest priority; only before the first training
- * call, else OSI_ERR_STATE). Unknown name -> OSI_ERR_ARG. */
+ * call, else OSI_ERR_STATE), "stage_join" (default 1; see osi_resnet50_grads_ready), "stagger", "stem_fused", "stem_pool_stats", "ds_sparse",
+ * "stem_wgrad_main" (A/B switches of the backward schedule). Unknown name -> OSI_ERR_ARG. */
 int osi_resnet50_set_option(osi_resnet50_t net, const char* name, int value);
 
 /* Optional HIP-event instrumentation of the executor (bench.py's roofline leg): one event after every op on the launch

@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1, /*tail_gain*/ 8, /*tail_qmax*/ 8, /*bn_grid_bwd*/ 1024, /*bn_wide_p*/ 2048};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1, /*tail_gain*/ 8, /*tail_qmax*/ 8, /*bn_grid_bwd*/ 1024, /*bn_wide_p*/ 2048, /*wave_prio*/ 0, /*lds_prefetch*/ 0, /*dp_reserved_cus*/ 0};
 
 namespace {
 int* tuning_slot(const char* name) {
@@ -27,20 +27,38 @@ int* tuning_slot(const char* name) {
     if (!strcmp(name, "bn_grid_bwd")) return &g_osi_tuning.bn_grid_bwd;
     if (!strcmp(name, "tail_gain")) return &g_osi_tuning.tail_gain;
     if (!strcmp(name, "tail_qmax")) return &g_osi_tuning.tail_qmax;
+    if (!strcmp(name, "dp_reserved_cus")) return &g_osi_tuning.dp_reserved_cus;
+    if (!strcmp(name, "wave_prio")) return &g_osi_tuning.wave_prio;
+    if (!strcmp(name, "lds_prefetch")) return &g_osi_tuning.lds_prefetch;
     return nullptr;
 }
 }  // namespace
 
 extern "C" {
-int osi_abi_version(void) { return 4; }   // 4: osi_dgrad_fusion.addend_stride, osi_conv_dgrad accumulate = 2 (3: gate read-out, geometry, stem kernels)
+int osi_abi_version(void) { return 5; }   // 5: osi_resnet50_grads_ready, executor option "stage_join", knob "dp_reserved_cus", range-checked knobs, plan snapshot (4: addend_stride, accumulate = 2)
 int osi_set_tuning(const char* name, int value) {
     int* s = tuning_slot(name);
     if (!s) return OSI_ERR_ARG;
-    if ((s == &g_osi_tuning.wgrad_blocks || s == &g_osi_tuning.wgrad3_blocks) && value < 1) return OSI_ERR_ARG;
-    if (s == &g_osi_tuning.wgrad_nst && value != 1 && value != 2) return OSI_ERR_ARG;
-    if ((s == &g_osi_tuning.bn_grid || s == &g_osi_tuning.bn_grid_bwd) && value < 1) return OSI_ERR_ARG;
-    if (s == &g_osi_tuning.bn_single_p && value < 1) return OSI_ERR_ARG;
-    if (s == &g_osi_tuning.bn_wide_p && value < 0) return OSI_ERR_ARG;
+    // every knob has a range; a value outside it is refused instead of silently switching a plan off
+    OsiTuning& t = g_osi_tuning;
+    auto in = [&](int lo, int hi) { return value >= lo && value <= hi; };
+    bool good = true;
+    if (s == &t.wgrad_tile) good = value == 0 || value == 64;
+    else if (s == &t.wgrad_blocks || s == &t.wgrad3_blocks) good = in(1, 1 << 20);
+    else if (s == &t.wgrad_nst) good = in(1, 2);
+    else if (s == &t.bn_grid || s == &t.bn_grid_bwd) good = in(1, 1 << 20);
+    else if (s == &t.bn_single_p) good = in(1, 1 << 20);
+    else if (s == &t.bn_wide_p) good = in(0, 2048);
+    else if (s == &t.wgrad3 || s == &t.wgrad_group) good = in(0, 2);
+    else if (s == &t.fwd_wide || s == &t.dgrad_wide || s == &t.tail_split || s == &t.stem_direct) good = in(0, 1);
+    else if (s == &t.tail_cus) good = in(0, 4096);            // 0 = ask the device
+    else if (s == &t.tail_smax) good = in(1, 64);
+    else if (s == &t.tail_mint) good = in(1, 4096);
+    else if (s == &t.tail_gain) good = in(0, 100);
+    else if (s == &t.tail_qmax) good = in(0, 4096);
+    else if (s == &t.dp_reserved_cus) good = in(0, 128);
+    else if (s == &t.wave_prio || s == &t.lds_prefetch) good = in(0, 2);
+    if (!good) return OSI_ERR_ARG;
     *s = value;
     return OSI_OK;
 }
@@ -56,7 +74,7 @@ const char* osi_strerror(int code) {
         case OSI_OK: return "ok";
         case OSI_ERR_ARG: return "invalid argument (shape, pointer or alignment precondition)";
         case OSI_ERR_LAUNCH: return "HIP launch failed";
-        case OSI_ERR_STATE: return "executor called out of order";
+        case OSI_ERR_STATE: return "executor called out of order, or a plan-relevant tuning knob changed after osi_resnet50_create";
         default: return "unknown error";
     }
 }

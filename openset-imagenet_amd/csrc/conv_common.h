@@ -34,7 +34,8 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 
 
 // internal host helpers implemented in conv_igemm.hip
-int chip_cus();                      // CUs of the current device (osi_set_tuning("tail_cus") overrides; 256 when no device answers)
+int hw_cus();                        // CUs of the current device (256 when no device answers); no knob touches it
+int chip_cus();                      // CUs the fwd / dgrad launch plans balance for: "tail_cus" if set, else hw_cus() - "dp_reserved_cus"
 bool conv_desc_ok(const osi_conv_desc* d);
 bool conv_is_stem(const osi_conv_desc* d);
 // out[i] = sum over s of slab[s * stride4 + i] (float4 units), fixed order: bitwise reproducible

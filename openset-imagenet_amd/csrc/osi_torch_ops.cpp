@@ -3,6 +3,7 @@
 //
 //   torch.ops.osi.resnet50_forward    model.py:28-39   (logits, features = model(images))
 //   torch.ops.osi.resnet50_backward   train.py:138     (j.backward() through the network, stage range for the DP bucket schedule)
+//   torch.ops.osi.resnet50_grads_ready  config/train.yaml:18,35-39 (hand a finished stage's gradients to the communication stream)
 //   torch.ops.osi.loss_fwd_bwd        losses.py:16-29, train.py:343-347 (the three losses + objectosphere term, value and gradient)
 //   torch.ops.osi.adam_step / sgd_step    train.py:139, 356-359
 //   torch.ops.osi.stage_canvas        train.py:259-263 after decode + resize (crop, flip, ToTensor, NHWC4)
@@ -111,6 +112,15 @@ void resnet50_backward(int64_t net, const Tensor& params, Tensor grads, Tensor w
        "osi_resnet50_backward");
 }
 
+// Data parallel: the stream `waiter` (a raw hipStream_t handle: torch.cuda.Stream.cuda_stream of the communication stream) waits for the
+// gradients of the backward stages enqueued so far on the CURRENT stream and on the executor's side stream; the current stream waits for nothing
+void resnet50_grads_ready(int64_t net, const Tensor& grads, int64_t waiter) {
+    need(grads, at::kFloat, "grads");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(grads.device());
+    ok(osi_resnet50_grads_ready(handle(net), stream_of(grads), reinterpret_cast<osi_stream_t>(static_cast<uintptr_t>(waiter))),
+       "osi_resnet50_grads_ready");
+}
+
 // returns (loss [], dlogits [B,C] or empty, dfeatures [B,F] or empty)
 std::tuple<Tensor, Tensor, Tensor> loss_fwd_bwd(int64_t mode, const Tensor& logits, const Tensor& target, double unk_weight,
                                                 int64_t ignore_index, const std::optional<Tensor>& class_weights,
@@ -192,6 +202,7 @@ TORCH_LIBRARY(osi, m) {
           "int fc_dim, int out_features, bool training) -> (Tensor, Tensor)");
     m.def("resnet50_backward(int net, Tensor params, Tensor(a!) grads, Tensor(b!) workspace, Tensor dlogits, Tensor? dfeatures, "
           "int stage_lo, int stage_hi) -> ()");
+    m.def("resnet50_grads_ready(int net, Tensor grads, int waiter_stream) -> ()");
     m.def("loss_fwd_bwd(int mode, Tensor logits, Tensor target, float unk_weight, int ignore_index, Tensor? class_weights, "
           "Tensor? features, float xi, float alpha, bool need_grad) -> (Tensor, Tensor, Tensor)");
     m.def("adam_step(Tensor(a!) params, Tensor grads, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, float beta2, "
@@ -206,6 +217,7 @@ TORCH_LIBRARY(osi, m) {
 TORCH_LIBRARY_IMPL(osi, CUDA, m) {
     m.impl("resnet50_forward", &resnet50_forward);
     m.impl("resnet50_backward", &resnet50_backward);
+    m.impl("resnet50_grads_ready", &resnet50_grads_ready);
     m.impl("loss_fwd_bwd", &loss_fwd_bwd);
     m.impl("adam_step", &adam_step);
     m.impl("sgd_step", &sgd_step);

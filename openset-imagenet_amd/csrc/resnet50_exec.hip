@@ -163,8 +163,24 @@ struct osi_resnet50 {
                                      // kernels never co-run, only HBM-bound work overlaps them. A/B against the default co-running schedule.
     struct PendingW { bool on = false; int ci = 0, gi = 0, in_bn = -1; const float* conv_in = nullptr; float* grads = nullptr; float* ws = nullptr; } pend;
     bool w_inflight = false;
+    int dbg_skip = 0;                // option "dbg_skip" (TIMING EXPERIMENTS ONLY, results are wrong): bit 0 = the BatchNorm-backward apply passes
+                                     // are not launched (their reductions still are), bit 1 = the block-output passes of the forward are
+                                     // not launched, bit 2 = with "fwd_recompute" the deferred block-output pass is not launched either — upper bounds for what folding
+                                     // those passes into their consumers could buy
+    bool stage_join = true;          // option "stage_join": a staged backward call (stage_hi < stages) ends by joining the side stream into
+                                     // the caller's stream. 0 (data parallel): only the LAST stage joins; the caller hands each finished
+                                     // stage to its communication stream with osi_resnet50_grads_ready, and the compute stream runs on
+    OsiTuning plan_knobs;            // the process-wide knobs the workspace was sized for (osi_resnet50_create); a launch under other
+    int plan_hw_cus = 0;             // values is refused (OSI_ERR_STATE) instead of running a plan the workspace does not fit
+    bool plan_unchanged() const {
+        const OsiTuning &a = plan_knobs, &b = g_osi_tuning;
+        return a.wgrad_tile == b.wgrad_tile && a.wgrad_blocks == b.wgrad_blocks && a.wgrad3 == b.wgrad3 && a.wgrad3_blocks == b.wgrad3_blocks &&
+               a.tail_split == b.tail_split && a.tail_cus == b.tail_cus && a.tail_smax == b.tail_smax && a.tail_mint == b.tail_mint &&
+               a.tail_gain == b.tail_gain && a.tail_qmax == b.tail_qmax && a.stem_direct == b.stem_direct && a.wgrad_group == b.wgrad_group &&
+               a.dp_reserved_cus == b.dp_reserved_cus;
+    }
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wdone = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wdone = nullptr, ev_rmain = nullptr, ev_rside = nullptr;
     hipEvent_t buf_ev[NSCR] = {};
     bool buf_pending[NSCR] = {};
     bool side_dirty = false;
@@ -211,6 +227,8 @@ struct osi_resnet50 {
             for (int i = 0; i < NSCR; ++i) (void)hipEventDestroy(buf_ev[i]);
             (void)hipStreamDestroy(side);
         }
+        if (ev_rmain) (void)hipEventDestroy(ev_rmain);
+        if (ev_rside) (void)hipEventDestroy(ev_rside);
     }
 };
 
@@ -289,8 +307,10 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
     n->bn_ws_bytes = bnws; n->bn_ws = n->ws_alloc(bnws / 4 + 4); n->bn_ws2 = n->ws_alloc(bnws / 4 + 4);
     n->wg_ws_bytes = wgws; n->wg_ws = n->ws_alloc(wgws / 4 + 4);
     // the fused stem weight gradient has its own slab: it may run on the main stream while the side stream still owns wg_ws
+    // (0 bytes = a geometry / knob setting the fused form does not take: the executor then never calls it — see stem_fused_ok)
     n->stem_ws_bytes = osi_stem_wgrad_fused_workspace(&n->convs[0].d);
     n->stem_ws = n->stem_ws_bytes ? n->ws_alloc(n->stem_ws_bytes / 4 + 4) : n->wg_ws;
+    n->plan_knobs = g_osi_tuning;
     n->dg_ws_bytes = dgws; n->dg_ws = n->ws_alloc(dgws / 4 + 4);
     n->scratch_floats = maxact;
     for (int i = 0; i < osi_resnet50::NSCR; ++i) n->scratch[i] = n->ws_alloc(maxact);
@@ -433,6 +453,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
                          void* workspace, float* logits, float* features, int training, osi_stream_t stream) {
     OSI_REQUIRE(n && params && buffers && workspace && logits && features);
     OSI_REQUIRE(!training || nbt);
+    if (!n->plan_unchanged()) return OSI_ERR_STATE;   // a plan-relevant knob changed after create: the workspace no longer fits the plans
     const float* ext = n->x4_ext;
     n->x4_ext = nullptr;
     if (!image && !ext && n->staged_ws != workspace) return OSI_ERR_STATE;   // image = NULL needs a staged or bound input
@@ -475,7 +496,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
             forked = true;
         }
         const Block* pk = bi > 0 ? &n->blocks[bi - 1] : nullptr;
-        if (deferred) {             // materialise the previous block's output (this block's shortcut / projection input)
+        if (deferred && !(n->dbg_skip & 4)) {   // materialise the previous block's output (this block's shortcut / projection input)
             Conv& c3p = n->convs[pk->c3];
             BN& b3p = n->bns[c3p.bn];
             OSI_TRY(osi_bn_apply_relu_mask(ws + c3p.y, ws + pk->x_in, ws + b3p.scale, ws + b3p.shift, ws + c3p.a, ws + c3p.mask, b3p.M,
@@ -501,6 +522,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
         BN& b3 = n->bns[c3.bn];
         deferred = n->fwd_recompute && k.ds < 0 && bi + 1 < nb;
         if (deferred) continue;     // the next iteration enqueues this block's output pass beside its conv1
+        if (n->dbg_skip & 2) continue;   // timing experiment: no block-output pass (the next block reads stale data)
         if (k.ds >= 0) {
             Conv& cd = n->convs[k.ds];
             BN& bd = n->bns[cd.bn];
@@ -623,6 +645,10 @@ static int bn_bwd_fused(osi_resnet50* n, int ci, const float* params, float* gra
     BN& b = n->bns[c.bn];
     const float* psum_g = ws + n->dg_ws;
     const float* psum_gx = psum_g + (size_t)(1 + which) * n->fused_P * b.C;
+    if (n->dbg_skip & 1) {   // timing experiment: reductions only, the consumers read whatever the dy buffer holds
+        OSI_TRY(osi_bn_backward_reduce(psum_g, psum_gx, n->fused_P, grads + b.g_off, grads + b.b_off, b.M, b.C, ws + n->bn_ws, n->bn_ws_bytes, st));
+        return n->mark(OSI_PROF_BN_BWD, st);
+    }
     OSI_TRY(osi_bn_backward_fused(ws + n->scratch[gi], ws + c.y, ws + b.mean, ws + b.invstd, params + b.g_off, psum_g, psum_gx,
                                   n->fused_P, ws + n->scratch[dyi], grads + b.g_off, grads + b.b_off, b.M, b.C, ws + n->bn_ws,
                                   n->bn_ws_bytes, st));
@@ -741,7 +767,7 @@ static int block_backward(osi_resnet50* n, int bi, const float* params, float* g
         // stem needs no reduction pass over its 112 x 112 tensor (pool mode of osi_conv_dgrad_fused)
         Conv& c0 = n->convs[0];
         n->stem_stats_P = 0;
-        if (n->stem_fused && n->stem_pool_stats && osi_stem_wgrad_fused_workspace(&c0.d) > 0) {
+        if (n->stem_fused && n->stem_pool_stats && n->stem_ws_bytes > 0) {
             BN& b0 = n->bns[c0.bn];
             osi_dgrad_fusion f{};
             f.y0 = ws + c0.y; f.mean0 = ws + b0.mean; f.invstd0 = ws + b0.invstd;
@@ -767,7 +793,7 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
                           const float* dfeatures, int stage_lo, int stage_hi, osi_stream_t stream) {
     OSI_REQUIRE(n && params && grads && workspace);
     OSI_REQUIRE(stage_lo >= 0 && stage_lo < stage_hi && stage_hi <= n->n_stages);
-    if (!n->fwd_done || stage_lo != n->next_stage) return OSI_ERR_STATE;
+    if (!n->fwd_done || stage_lo != n->next_stage || !n->plan_unchanged()) return OSI_ERR_STATE;
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     auto S = [&](int i) { return ws + n->scratch[i]; };
@@ -811,7 +837,7 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
             if (t < 0) return t;
             BN& b0 = n->bns[c0.bn];
             const float* x4c = n->x4_cur ? n->x4_cur : ws + n->x4;
-            if (n->stem_fused && osi_stem_wgrad_fused_workspace(&c0.d) > 0) {
+            if (n->stem_fused && n->stem_ws_bytes > 0) {      // its own slab, sized at create: never the side stream's wg_ws
                 // reductions of bn1's backward (dgamma, dbeta) on the main stream, then the weight gradient with the max-pool scatter,
                 // ReLU gate and BatchNorm backward applied inside its operand loader: the 112x112x64 gradient is never written
                 n->give(t);
@@ -836,8 +862,7 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
                     gs = n->side;
                 }
                 OSI_TRY(osi_stem_wgrad_fused(&c0.d, S(go), ws + n->pool_idx, ws + c0.y, x4c, params + b0.g_off, ws + b0.mean, ws + b0.invstd,
-                                             grads + b0.g_off, grads + b0.b_off, grads + c0.w_off, ws + n->stem_ws,
-                                             n->stem_ws_bytes ? n->stem_ws_bytes : n->wg_ws_bytes, gs));
+                                             grads + b0.g_off, grads + b0.b_off, grads + c0.w_off, ws + n->stem_ws, n->stem_ws_bytes, gs));
                 if (async) {
                     if (hipEventRecord(n->buf_ev[go], n->side) != hipSuccess) return OSI_ERR_LAUNCH;
                     n->buf_pending[go] = true;
@@ -862,8 +887,28 @@ int osi_resnet50_backward(osi_resnet50_t n, const float* params, float* grads, v
     // Join once per call: every gradient of the stages just run is final on `st` from here on. A data-parallel caller issues
     // one stage per call (and reduces that slice next); a single-GPU caller issues all stages in one call and pays one join.
     OSI_TRY(flush_wgrad(n, st));
-    n->w_inflight = false;             // the join below covers it
-    OSI_TRY(n->join_side(st));
+    if (n->stage_join || stage_hi == n->n_stages) {
+        n->w_inflight = false;         // the join below covers it
+        OSI_TRY(n->join_side(st));
+    }
+    return OSI_OK;
+}
+
+// Hand the gradients of the stages enqueued so far to another stream WITHOUT stalling the compute stream: `waiter` waits for the
+// work enqueued on `main` up to now and for the side stream's weight gradients; `main` waits for nothing.
+int osi_resnet50_grads_ready(osi_resnet50_t n, osi_stream_t main_stream, osi_stream_t waiter_stream) {
+    OSI_REQUIRE(n);
+    hipStream_t mn = (hipStream_t)main_stream, wt = (hipStream_t)waiter_stream;
+    if (!n->ev_rmain) {
+        if (hipEventCreateWithFlags(&n->ev_rmain, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&n->ev_rside, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
+    }
+    if (hipEventRecord(n->ev_rmain, mn) != hipSuccess) return OSI_ERR_LAUNCH;
+    if (hipStreamWaitEvent(wt, n->ev_rmain, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+    if (n->side && n->side_dirty) {
+        if (hipEventRecord(n->ev_rside, n->side) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipStreamWaitEvent(wt, n->ev_rside, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+    }
     return OSI_OK;
 }
 
@@ -970,6 +1015,8 @@ int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
     else if (!strcmp(name, "stem_pool_stats")) n->stem_pool_stats = value != 0;
     else if (!strcmp(name, "ds_sparse")) n->ds_sparse = value != 0;
     else if (!strcmp(name, "stem_wgrad_main")) n->stem_wgrad_main = value != 0;
+    else if (!strcmp(name, "stage_join")) n->stage_join = value != 0;
+    else if (!strcmp(name, "dbg_skip")) n->dbg_skip = value;
     else if (!strcmp(name, "side_priority_normal")) {
         if (n->side) return OSI_ERR_STATE;   // the side stream already exists with the other priority
         n->side_prio_normal = value != 0;

@@ -430,7 +430,7 @@ static bool stem_wgrad_direct_ok(const osi_conv_desc* d) { return stem_direct_ge
 static void stem_wgrad_plan(const osi_conv_desc* d, int& ntiles, int& per, int& groups) {
     ntiles = d->B * (d->Ho / SD_TH) * (d->Wo / SD_TW);
     // persistent workgroups, three per CU (41 KB of LDS each): one partial slab per workgroup
-    const int want = 3 * chip_cus();
+    const int want = 3 * hw_cus();     // the hardware's CUs, not the fwd / dgrad plan's ("tail_cus" must not resize this grid or its slab)
     per = osi_cdiv(ntiles, want);
     if (per < 1) per = 1;
     groups = osi_cdiv(ntiles, per);

@@ -9,9 +9,11 @@ Design for point-to-point xGMI (7 links x ~153 GB/s per GPU, no switch):
   * the gradient arena is ONE contiguous fp32 buffer laid out in forward order; backward finishes it back to front in
     4 stages (head+layer4 = 15.2 M floats, layer3 = 7.1 M, layer2 = 1.2 M, layer1+stem = 0.2 M), so each bucket is one
     contiguous slice — no gather/scatter copies, 4 collectives per step instead of 162;
-  * `bucket_ready` issues `all_reduce(async_op=True)` on the slice as soon as its stage has been enqueued: the process
-    group's own side stream waits on the compute stream's progress and runs the ring while the compute stream continues
-    with the next stage; `finish()` makes the compute stream wait for all four before the optimizer step.
+  * `bucket_ready` issues the all-reduce of the slice as soon as its stage has been enqueued, from a communication stream that
+    waits for exactly the kernels that wrote the slice (the compute stream's progress and the executor's weight-gradient side
+    stream — osi_resnet50_grads_ready); the compute stream itself never waits between stages (round 4: the three per-stage joins
+    of the side stream are gone) and runs the next stage while the ring is on the wire; `finish()` makes it wait for all four
+    collectives before the optimizer step.
 On gloo (CPU tests) the same code averages with SUM + divide; on nccl (= RCCL) it uses ReduceOp.AVG in place.
 """
 import torch
@@ -22,11 +24,13 @@ from torch import nn
 class GradSync:
     """Bucketed asynchronous gradient averaging over a flat arena.
 
-    `timing(True)` switches to an instrumented form of the same schedule (bench.py's comm leg, never the timed region): each
-    bucket's collective is issued from a communication stream this object owns, bracketed by two HIP events on that stream
-    (ProcessGroupNCCL runs the ring on its internal stream and makes the issuing stream wait for it, so the bracket is the
-    collective's own duration plus its wait for the bucket's producer), and `finish()` measures how long the compute stream
-    still had to wait once backward was fully enqueued — the exposed part. `read_timing()` returns the per-step means."""
+    Device-resident buckets are reduced from a communication stream this object owns: the model hands each finished backward stage
+    to it (`handoff`), the collective is issued there in its synchronous form (ProcessGroupNCCL runs the ring on its internal stream
+    and makes the ISSUING stream — the communication stream — wait for it), and `finish()` makes the compute stream wait for the
+    communication stream once, in front of the optimizer. `timing(True)` (bench.py's comm leg, never the timed region) brackets every
+    collective with two HIP events on the communication stream — the first is recorded behind the hand-off, so the bracket is the
+    collective's own duration — and measures how long the compute stream still waited in `finish()`: the exposed part.
+    `read_timing()` returns the per-step means."""
 
     def __init__(self, process_group=None):
         self.group = process_group
@@ -38,31 +42,54 @@ class GradSync:
         self._ev = []            # per step: ([(start, end) per bucket], exposed_start, exposed_end)
         self._cur = None
         self._host = []          # gloo: host-side seconds per step (collectives complete on the host)
+        self._on_comm = False    # collectives of this step were issued from the communication stream
 
     def timing(self, on):
         self._timing = bool(on)
         self._ev, self._host, self._cur = [], [], None
 
-    def bucket_ready(self, flat, lo, hi):
+    def _comm(self, device):
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=device)
+        return self._comm_stream
+
+    def bucket_ready(self, flat, lo, hi, handoff=None):
+        """Average flat[lo:hi] across the ranks, asynchronously to the calling (compute) stream.
+
+        `handoff(comm_stream)` — given by the model for device-resident gradients — makes the communication stream wait for the
+        bucket's producers (the compute stream's progress AND the executor's side stream, torch.ops.osi.resnet50_grads_ready) without
+        making the compute stream wait for anything: the next backward stage is enqueued behind the previous one with no bubble, the
+        collective is ordered behind exactly the kernels that wrote the bucket. Without it (CPU tensors, stand-alone use) the
+        collective is ordered behind the current stream as torch.distributed does by default."""
         if self.world == 1 or hi <= lo:
             return
         bucket = flat[lo:hi]
-        if self.backend == "nccl":
-            if self._timing and bucket.is_cuda:
-                if self._comm_stream is None:
-                    self._comm_stream = torch.cuda.Stream(device=bucket.device)
-                comm = self._comm_stream
+        if bucket.is_cuda and (handoff is not None or self._timing):
+            comm = self._comm(bucket.device)
+            if handoff is not None:
+                handoff(comm)
+            else:
                 comm.wait_stream(torch.cuda.current_stream(bucket.device))
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                with torch.cuda.stream(comm):
-                    e0.record(comm)
+            ev = None
+            with torch.cuda.stream(comm):
+                if self._timing:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(comm)
+                # synchronous form ON THE COMMUNICATION STREAM: that stream (not the host, not the compute stream) waits for the ring
+                if self.backend == "nccl":
                     dist.all_reduce(bucket, op=dist.ReduceOp.AVG, group=self.group)
-                    e1.record(comm)
+                else:
+                    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+                    bucket.div_(self.world)
+                if ev is not None:
+                    ev[1].record(comm)
+            if ev is not None:
                 if self._cur is None:
                     self._cur = []
-                self._cur.append((e0, e1))
-                self._work.append((None, None))
-                return
+                self._cur.append(ev)
+            self._on_comm = True
+            return
+        if self.backend == "nccl":
             w = dist.all_reduce(bucket, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             self._work.append((w, None))
         else:
@@ -70,22 +97,25 @@ class GradSync:
             self._work.append((w, bucket))
 
     def finish(self):
-        timed_dev = self._timing and self._comm_stream is not None and self._cur is not None
-        if timed_dev:
+        """The calling stream waits for every collective issued since the last finish() (the optimizer step follows)."""
+        if self._on_comm:
             cur = torch.cuda.current_stream(self._comm_stream.device)
-            x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            x0.record(cur)
+            timed = self._timing and self._cur is not None
+            if timed:
+                x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                x0.record(cur)
             cur.wait_stream(self._comm_stream)
-            x1.record(cur)
-            self._ev.append((self._cur, x0, x1))
-            self._cur = None
+            if timed:
+                x1.record(cur)
+                self._ev.append((self._cur, x0, x1))
+                self._cur = None
+            self._on_comm = False
         t0 = None
-        if self._timing and not timed_dev and self._work:
+        if self._timing and self._work:
             import time
             t0 = time.perf_counter()
         for w, bucket in self._work:
-            if w is not None:
-                w.wait()  # nccl: the current stream waits for the side stream; gloo: host wait
+            w.wait()  # nccl: the current stream waits for the process group's stream; gloo: host wait
             if bucket is not None:
                 bucket.div_(self.world)
         if t0 is not None:

@@ -51,6 +51,8 @@ def debug_options_from_env():
     out = {}
     if env.get("OSI_NO_OVERLAP"):
         out["overlap"] = 0
+    if env.get("OSI_DBG_SKIP"):          # timing experiments only (wrong results): see the executor's "dbg_skip"
+        out["dbg_skip"] = int(env["OSI_DBG_SKIP"])
     if env.get("OSI_FWD_RECOMPUTE") == "1":
         out["fwd_recompute"] = 1
     if env.get("OSI_FWD_FORK") == "0":
@@ -77,6 +79,7 @@ class _Net:
         self.h = ctypes.c_void_p()
         N.check(N.lib().osi_resnet50_create(ctypes.byref(self.h), B, H, W, F, O, int(bool(logit_bias))), "osi_resnet50_create")
         self.ws_bytes = N.lib().osi_resnet50_workspace_bytes(self.h)
+        self.staged = False      # executor option "stage_join" = 0 has been set (data-parallel backward)
         for name, value in debug_options_from_env().items():
             N.check(N.lib().osi_resnet50_set_option(self.h, name.encode(), value), f"osi_resnet50_set_option({name})")
 
@@ -320,10 +323,15 @@ class ResNet50(nn.Module):
         if sync is None:  # single GPU: all stages in one call (one side-stream join at the end)
             bwd(net.h.value, self._flat_params, self._flat_grads, self._ws, dlogits, dfeatures, 0, self._n_stages)
         else:             # data parallel: stage by stage, each finished slice of the gradient arena goes to the all-reduce
+            if not net.staged:   # staged calls no longer join the weight-gradient side stream into the compute stream (only the last does)
+                N.check(N.lib().osi_resnet50_set_option(net.h, b"stage_join", 0), "osi_resnet50_set_option(stage_join)")
+                net.staged = True
+            grads = self._flat_grads
+            handoff = lambda comm: N.ops().resnet50_grads_ready(net.h.value, grads, comm.cuda_stream)
             for s in range(self._n_stages):
-                bwd(net.h.value, self._flat_params, self._flat_grads, self._ws, dlogits, dfeatures, s, s + 1)
+                bwd(net.h.value, self._flat_params, grads, self._ws, dlogits, dfeatures, s, s + 1)
                 lo, hi = self._stage_ranges[s]
-                sync.bucket_ready(self._flat_grads, lo, hi)
+                sync.bucket_ready(grads, lo, hi, handoff)
             sync.finish()
         self._grads_fresh = True
         self.bind_gradients()

@@ -83,6 +83,14 @@ def test_bench_two_rank_rehearsal_reports_the_proof_of_ranks(cuda):
     assert len(r["buckets"]) == 4 and r["allreduce_bytes_per_step"] == sum(b["bytes"] for b in r["buckets"])
     assert 4 * 23570402 <= r["allreduce_bytes_per_step"] <= 4 * 23570402 + 16 * 162
     assert r["exposed_comm_ms"] is not None and r["comm_steps"] >= 1
+    # self-diagnosing record: what EVERY rank saw (own finish times per window, exposed communication), not only the MAX
+    assert [q["rank"] for q in r["per_rank"]] == [0, 1] and all(len(q["own_ms_per_step_windows"]) == 3 for q in r["per_rank"])
+    assert all(q["exposed_comm_ms"] is not None for q in r["per_rank"])
+    pr = r["per_rank_ms_per_step"]
+    assert 0 < pr["min"] <= pr["median"] <= pr["max"] <= max(w) * 1.001
+    lp = r["launch_plan"]
+    assert lp["hw_cus"] == 256 and lp["tail_cus"] == 0 and lp["dp_reserved_cus"] == 0 and lp["tail_plan_cus_in_effect"] == 256 and lp["tail_split"] == 1
+    assert r["channels"] is None     # gloo rehearsal: no RCCL communicator
 
 
 @pytest.mark.timeout(900)
@@ -95,3 +103,17 @@ def test_bench_force_dp_world1_runs_the_rccl_path(cuda):
     assert len(r["per_bucket_comm_ms"]) == 4 and all(v >= 0 for v in r["per_bucket_comm_ms"])
     assert r["comm_ms_per_step"] == pytest.approx(sum(r["per_bucket_comm_ms"]), abs=2e-3) and r["exposed_comm_ms"] >= 0
     assert len(out["windows_ms_per_step"]) == 3
+    assert len(r["per_rank"]) == 1 and r["per_rank"][0]["exposed_comm_ms"] == r["exposed_comm_ms"]
+    ch = r["channels"]
+    assert set(ch) >= {"coll_channels", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "source"}
+    print("RCCL channels:", ch)
+
+
+@pytest.mark.timeout(900)
+def test_bench_dp_reserved_cus_reaches_the_launch_plan(cuda):
+    """OSI_DP_RESERVED_CUS (the wave slots left to RCCL's resident channel workgroups) travels environment -> osi_set_tuning ->
+    plan_tail_split's CU count, and the record says which plan was in effect."""
+    out = _run_bench(["--steps", "1", "--warmup", "1", "--windows", "1", "--batch", "8", "--no-cpu-baseline", "--no-profile", "--force-dp"],
+                     {"OSI_DP_RESERVED_CUS": "8"}, 1)
+    lp = out["rccl"]["launch_plan"]
+    assert lp["dp_reserved_cus"] == 8 and lp["tail_plan_cus_in_effect"] == 248

@@ -105,6 +105,7 @@ def test_config_meters_and_loss_factory(tmp_path):
     cfg.loss.type = "garbage"
     with pytest.raises(ValueError):
         build_loss(cfg, 30)
+    tools.set_device_cpu()       # (a GPU test earlier in the same process may have selected cuda:0)
     assert tools.device(torch.zeros(1)).device.type == "cpu" and tools.get_device().type == "cpu"
 
 

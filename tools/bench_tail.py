@@ -1,6 +1,7 @@
 """Dev tool: the forward / input-gradient convolutions exactly as the executor calls them (statistics epilogue, fused input
 activation, fused dgrad epilogue), with the balanced remainder (osi_set_tuning("tail_split")) off and on, interleaved in ONE
-process on the same buffers (variants A/B/A/B..., median of the rounds). Usage: python tools/bench_tail.py [B] [rounds] [fwd|dgrad|both]"""
+process on the same buffers (variants A/B/A/B..., median of the rounds). Usage: python tools/bench_tail.py [B] [rounds] [fwd|dgrad|both]
+Any other process-wide knob can take the place of tail_split: OSI_AB_KNOB=wave_prio OSI_AB_VALUES=0,2 (restored to the first value)."""
 import ctypes, os, statistics, sys, time
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "openset-imagenet_amd")]
@@ -16,6 +17,8 @@ SHAPES = [(64, 64, 1, 1, 56, 1, 0), (64, 64, 3, 1, 56, 3, 1), (64, 256, 1, 1, 56
           (512, 256, 1, 1, 28, 1, 0), (256, 256, 3, 2, 28, 1, 1), (256, 1024, 1, 1, 14, 6, 1), (512, 1024, 1, 2, 28, 1, 0), (1024, 256, 1, 1, 14, 5, 0),
           (256, 256, 3, 1, 14, 5, 1), (1024, 512, 1, 1, 14, 1, 0), (512, 512, 3, 2, 14, 1, 1), (512, 2048, 1, 1, 7, 3, 1), (1024, 2048, 1, 2, 14, 1, 0),
           (2048, 512, 1, 1, 7, 2, 0), (512, 512, 3, 1, 7, 2, 1)]
+KNOB = os.environ.get("OSI_AB_KNOB", "tail_split").encode()
+VA, VB = (int(v) for v in os.environ.get("OSI_AB_VALUES", "0,1").split(","))
 L = N.lib()
 S = lambda: torch.cuda.current_stream().cuda_stream
 dev = torch.device("cuda")
@@ -47,18 +50,18 @@ def timed(fn, reps=10):
 
 def ab(fn):
     """median ms of fn with tail_split 0 and 1, interleaved rounds, each after a burst that keeps the clock settled"""
-    t = {0: [], 1: []}
+    t = {VA: [], VB: []}
     for r in range(ROUNDS):
-        for v in (0, 1) if r % 2 == 0 else (1, 0):
-            N.check(L.osi_set_tuning(b"tail_split", v))
+        for v in (VA, VB) if r % 2 == 0 else (VB, VA):
+            N.check(L.osi_set_tuning(KNOB, v))
             burst(fn)
             t[v].append(timed(fn))
-    N.check(L.osi_set_tuning(b"tail_split", 1))
-    return statistics.median(t[0]), statistics.median(t[1])
+    N.check(L.osi_set_tuning(KNOB, 1 if KNOB == b"tail_split" else VA))
+    return statistics.median(t[VA]), statistics.median(t[VB])
 
 
 tot = {"fwd": [0.0, 0.0, 0.0], "dgrad": [0.0, 0.0, 0.0]}
-print(f"B={B}: TFLOP/s as the executor calls it, tail split off -> on (median of {ROUNDS} interleaved rounds)")
+print(f"B={B}: TFLOP/s as the executor calls it, {KNOB.decode()} {VA} -> {VB} (median of {ROUNDS} interleaved rounds)")
 for Cin, Cout, k, s, H, cnt, fused in SHAPES:
     pad = 1 if k == 3 else 0
     d = N.ConvDesc.make(B, H, H, Cin, Cout, k, s, pad)
