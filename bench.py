@@ -299,7 +299,7 @@ def main():
             # RCCL has no API for its channel count (= the workgroups a collective keeps resident on this GPU): read it from the
             # communicator's own INIT log, written to a private file (stdout stays one JSON line)
             rccl_log = f"/tmp/osi_rccl_init_{os.getpid()}.log"
-            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=rccl_log)
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_FILE=rccl_log)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -314,6 +314,10 @@ def main():
     net = DistributedDataParallel(model) if use_dp else model
     if args.force_dp and world == 1:
         net.sync.world = 2   # AVG over one rank is the identity; the collectives are still enqueued
+        if os.environ.get("OSI_BENCH_SKIP_COLLECTIVE") == "1":   # dev: price the staged backward + hand-off WITHOUT RCCL's kernels
+            dist.all_reduce = lambda *a, **k: None
+        elif os.environ.get("OSI_BENCH_SKIP_COLLECTIVE") == "2": # dev: the four staged backward calls alone (no hand-off either)
+            net.sync.world = 1
     opt = optim.Adam(model.parameters(), lr=1e-3)
     images, labels = synthetic_batch(B, C, wl["p_neg"], wl["loss"], dev, 42 + rank)
     if wl["loss"] == "garbage":

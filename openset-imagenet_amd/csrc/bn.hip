@@ -146,8 +146,8 @@ __global__ __launch_bounds__(NT) void k_bn_stats_final_rows(const float* __restr
     }
 }
 // Single-launch finalisation for mid-sized P (round 3): 16 channels x 64 partial lanes per workgroup, ONE pass over the partials with
-// four independent loads in flight per lane. Shifted sums with the first tile's mean as pivot (within a few sigma / sqrt(rows) of the
-// batch mean, so S2 - S1^2 / M does not cancel):  S1 = sum n_b (mean_b - pv),  S2 = sum [ M2_b + n_b (mean_b - pv)^2 ],
+// four independent loads in flight per lane. Shifted sums around a pivot pv close to the batch mean (the average of 64 tile means, so
+// that S2 - S1^2 / M does not cancel):  S1 = sum n_b (mean_b - pv),  S2 = sum [ M2_b + n_b (mean_b - pv)^2 ],
 // mean = pv + S1 / M,  M2 = S2 - S1^2 / M. Fixed summation order (lane stride, then lanes in order): bitwise reproducible.
 constexpr int WPL = 64;   // partial lanes of the wide finalisers
 __device__ __forceinline__ float wide_reduce(float (*red)[16], float v, int pl, int cl) {
@@ -178,27 +178,35 @@ __global__ __launch_bounds__(16 * WPL) void k_bn_stats_final_wide(const float* _
     const bool ok = blockIdx.x * 16 + cl < C;
     const int last = P - 1;
     const float nfull = (float)rows_per_blk, nlast = (float)(M - last * rows_per_blk);
-    const float pv = pmean[c];
     const float* pa = pmean + c;
     const float* pb = pm2 + c;
+    // pivot = the average of the first 64 tile means (one per partial lane; lanes past P repeat the last tile). A single tile's mean —
+    // the first tile is the top-left corner of image 0: border pixels — can sit many sigma from the batch mean, and S2 - S1^2 / M then
+    // cancels (relative error ~ eps * (pivot offset / sigma)^2); the average of 64 tiles is within a fraction of sigma of it whatever
+    // one tile does. Costs one more reduction of values the lanes load anyway.
+    const float pv = wide_reduce(red, pa[(size_t)min(pl, last) * C], pl, cl) * (1.f / WPL);
+    if (pl == 0) red[0][cl] = pv;          // wide_reduce returns the sum to pl == 0 only: hand it to the channel's other lanes
+    __syncthreads();
+    const float pvv = red[0][cl];
+    __syncthreads();
     float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
     int b = pl;
     for (; b + 3 * WPL < P; b += 4 * WPL) {
         const float m0 = pa[(size_t)b * C], m1 = pa[(size_t)(b + WPL) * C], m2_ = pa[(size_t)(b + 2 * WPL) * C], m3 = pa[(size_t)(b + 3 * WPL) * C];
         const float q0 = pb[(size_t)b * C], q1 = pb[(size_t)(b + WPL) * C], q2 = pb[(size_t)(b + 2 * WPL) * C], q3 = pb[(size_t)(b + 3 * WPL) * C];
-        const float d0 = m0 - pv, d1 = m1 - pv, d2 = m2_ - pv, d3 = m3 - pv;
+        const float d0 = m0 - pvv, d1 = m1 - pvv, d2 = m2_ - pvv, d3 = m3 - pvv;
         const float n3 = b + 3 * WPL == last ? nlast : nfull;     // only the last of the four can be the ragged tile
         s1a += nfull * d0; s1b += nfull * d1; s1a += nfull * d2; s1b += n3 * d3;
         s2a += q0 + nfull * d0 * d0; s2b += q1 + nfull * d1 * d1; s2a += q2 + nfull * d2 * d2; s2b += q3 + n3 * d3 * d3;
     }
     for (; b < P; b += WPL) {
-        const float d = pa[(size_t)b * C] - pv, n = b == last ? nlast : nfull;
+        const float d = pa[(size_t)b * C] - pvv, n = b == last ? nlast : nfull;
         s1a += n * d; s2a += pb[(size_t)b * C] + n * d * d;
     }
     const float S1 = wide_reduce(red, s1a + s1b, pl, cl);
     const float S2 = wide_reduce(red, s2a + s2b, pl, cl);
     if (pl == 0 && ok) {
-        const float mean = pv + S1 / (float)M;
+        const float mean = pvv + S1 / (float)M;
         const float m2 = fmaxf(S2 - S1 * S1 / (float)M, 0.f);
         bn_finish(c, mean, m2, M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
     }
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(16 * WPL) void k_bn_stats_final_wide(const float* _
 __global__ __launch_bounds__(NT) void k_bn_stats_group(const float* __restrict__ pmean, const float* __restrict__ pm2, int P, int Pc,
                                                       int rows_per_blk, int M, int C, int S, float* __restrict__ gmean,
                                                       float* __restrict__ gm2) {
-    // one pass of shifted sums (pivot = the group's first tile mean), four row tiles in flight per lane; see k_bn_stats_final_wide
+    // one pass of shifted sums, four row tiles in flight per lane; see k_bn_stats_final_wide
     __shared__ float red[2][16][16];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = min(blockIdx.x * 16 + cl, C - 1), s = blockIdx.y;
@@ -218,7 +226,14 @@ __global__ __launch_bounds__(NT) void k_bn_stats_group(const float* __restrict__
     const float ng = (float)(min(M, b1 * rows_per_blk) - b0 * rows_per_blk);
     const float* pa = pmean + c;
     const float* pb = pm2 + c;
-    const float pv = pa[(size_t)b0 * C];
+    // pivot = the average of the group's first 16 tile means (see k_bn_stats_final_wide)
+    red[0][pl][cl] = pa[(size_t)min(b0 + pl, b1 - 1) * C];
+    __syncthreads();
+    float pv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pv += red[0][k][cl];
+    pv *= 1.f / 16.f;
+    __syncthreads();
     float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
     int b = b0 + pl;
     for (; b + 48 < b1; b += 64) {

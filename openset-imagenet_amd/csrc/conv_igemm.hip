@@ -78,7 +78,6 @@ struct ConvP {
     // ks_slab[((mt - MT1) * NT + nt) * ks_S + split]; k_conv_tail_fixup adds the splits in fixed order and finishes the epilogue
     int MT1, g1, ks_S, ks_T;
     float* ks_slab;
-    int prio;         // fwd / dgrad: 1 = wave priority follows the workgroup's progress through its K loop (see wave_prio_step)
 #ifdef OSI_STAMPS
     unsigned long long* stamps;   // diagnostic build only (make stamps): 8 words per workgroup, see tools/wg_timeline.py
 #endif
@@ -135,20 +134,6 @@ __device__ __forceinline__ bool tile_of_block_split(const ConvP& p, int bid, int
     return mt < p.MT;
 }
 
-// Wave priority by progress. The SIMD's arbiter issues from the highest-priority wave and, among equals, from the OLDEST: with
-// every workgroup of a launch resident at once (the 14x14 / 7x7 layers: 3-7 per CU) the oldest workgroups run at full speed and
-// leave after a quarter of the launch, the youngest crawl, and the launch ends with one or two waves per SIMD exposed to every
-// load latency (tools/wg_timeline.py: resident workgroups per CU fall steadily from 25 % of the span on). With the user priority
-// (s_setprio, 0-3) stepping DOWN as a workgroup passes the quarters of its K loop, whoever has more work left goes first: the
-// workgroups of a CU advance together and leave together, and the tail at low occupancy shrinks to the last quarter's spread.
-__device__ __forceinline__ void wave_prio_step(int on, int t, int q1, int q2, int q3) {
-    if (on) {
-        if (t == q1) __builtin_amdgcn_s_setprio(2);
-        else if (t == q2) __builtin_amdgcn_s_setprio(1);
-        else if (t == q3) __builtin_amdgcn_s_setprio(0);
-    }
-}
-
 // ---- MFMA over one LDS stage -------------------------------------------------------------------------
 // A: R image (rows = GEMM rows), B: R image (rows = GEMM cols)
 // [J0, J1) of the 4 sub-steps of 8 k each: a kernel may split the block to place other work between MFMAs of the same wave
@@ -170,35 +155,6 @@ __device__ __forceinline__ void mma_RR(const float* sA, const float* sB, int aro
 #pragma unroll
                 for (int n = 0; n < WN; ++n)
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[n][e], acc[i][n], 0, 0, 0);
-    }
-}
-// The same with the operand fragments of sub-step j + 1 read BEFORE the MFMAs of sub-step j (two register sets): the LDS round
-// trip of three of the four sub-steps hides behind the wave's own MFMAs instead of needing another wave to fill it. +8 registers
-// (WM = WN = 1): used where the launch cannot fill eight waves per SIMD anyway (see conv_fwd_impl, "lds_prefetch")
-template <int WM, int WN>
-__device__ __forceinline__ void mma_RR_pf(const float* sA, const float* sB, int arow, int brow, int lane, f32x16 (&acc)[WM][WN]) {
-    const int h4 = (lane >> 5) * 4, l31 = lane & 31;
-    f32x4 a[2][WM], b[2][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(sA + (arow + i * 32 + l31) * LDR + h4);
-#pragma unroll
-    for (int i = 0; i < WN; ++i) b[0][i] = *reinterpret_cast<const f32x4*>(sB + (brow + i * 32 + l31) * LDR + h4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = j & 1, nx = c ^ 1;
-        if (j < 3) {
-#pragma unroll
-            for (int i = 0; i < WM; ++i) a[nx][i] = *reinterpret_cast<const f32x4*>(sA + (arow + i * 32 + l31) * LDR + 8 * (j + 1) + h4);
-#pragma unroll
-            for (int i = 0; i < WN; ++i) b[nx][i] = *reinterpret_cast<const f32x4*>(sB + (brow + i * 32 + l31) * LDR + 8 * (j + 1) + h4);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int n = 0; n < WN; ++n)
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i][e], b[c][n][e], acc[i][n], 0, 0, 0);
     }
 }
 // A: R image, B: C image [32][LDC]
@@ -256,17 +212,14 @@ __device__ __forceinline__ void mma_CC(const float* sA, const float* sB, int aco
 // cost occupancy, which is what these kernels live on)
 // KS: the launch carries a K-split tail (tile_of_block_split); its own instantiation so that the plain kernels keep their scalar
 // register count (<= 80 SGPRs = eight resident 256-thread workgroups per CU)
-// PF: operand fragments prefetched one sub-step ahead (mma_RR_pf): +8 registers, seven waves per SIMD — for launches that cannot
-// fill eight anyway
-template <int WM, int WN, bool STEM, int NST, int XF = 0, bool KS = false, bool PF = false>
-__global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? (PF ? 7 : 8) : 5) : (NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2)) void k_conv_fwd(ConvP p) {
+template <int WM, int WN, bool STEM, int NST, int XF = 0, bool KS = false>
+__global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2)) void k_conv_fwd(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32, BR = BN / 32;  // float4 loads per thread per stage
     constexpr int STAGE = (BM + BN) * LDR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(!(XF && STEM), "the stem reads the image, not an activation");
     OSI_STAMP(p, blockIdx.x, 0); OSI_STAMP_ID(p, blockIdx.x);
-    if (p.prio) __builtin_amdgcn_s_setprio(3);
     float* s_sc = smem + NST * STAGE;          // XF: per-input-channel scale | shift tables, behind the operand stages
     float* s_sh = s_sc + p.Cin;
     if (XF) {
@@ -413,14 +366,11 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? (PF ? 7 : 8) : 5) : (NST 
     sstore(0);
     __syncthreads();
     OSI_STAMP(p, blockIdx.x, 1);
-    const int pq = (T - t0) >> 2, pq1 = t0 + pq, pq2 = t0 + 2 * pq, pq3 = t0 + 3 * pq;
     for (int t = t0; t < T; ++t) {
         const int buf = NST == 2 ? ((t - t0) & 1) : 0;
-        wave_prio_step(p.prio, t, pq1, pq2, pq3);
         if (t + 1 < T) { gload(t + 1); advance(); }
         const float* sA = smem + buf * STAGE;
-        if constexpr (PF) mma_RR_pf<WM, WN>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
-        else mma_RR<WM, WN>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
+        mma_RR<WM, WN>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
         if (NST == 1) __syncthreads();  // every wave is done reading the only stage
         if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
         __syncthreads();
@@ -701,7 +651,6 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ?
     const size_t sidx = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
 #endif
     OSI_STAMP(p, sidx, 0); OSI_STAMP_ID(p, sidx);
-    if (p.prio) __builtin_amdgcn_s_setprio(3);
 
     int mt, nt, ks = -1;
     if (KS) { if (!tile_of_block_split(p, blockIdx.x, mt, nt, ks)) return; }
@@ -815,11 +764,9 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ?
         sstore(0);
         __syncthreads();
         OSI_STAMP(p, sidx, 1);
-        const int pq = (T - t0) >> 2, pq1 = t0 + pq, pq2 = t0 + 2 * pq, pq3 = t0 + 3 * pq;
-        for (int t = t0; t < T; ++t) {
+            for (int t = t0; t < T; ++t) {
             const int buf = NST == 2 ? ((t - t0) & 1) : 0;
-            wave_prio_step(p.prio, t, pq1, pq2, pq3);
-            if (t + 1 < T) { gload(); advance(); }
+                if (t + 1 < T) { gload(); advance(); }
             const float* sA = smem + buf * STAGE;
             mma_RC<WM, WN, LDC>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
             if (NST == 1) __syncthreads();
@@ -1543,18 +1490,6 @@ static ConvP make_p(const osi_conv_desc* d) {
 #endif
     return p;
 }
-// "lds_prefetch": 0 off; 1 = the operand-prefetching 64x64 forward kernel (seven waves per SIMD) for launches of at most seven
-// workgroups per CU; 2 = for every 64x64 forward launch (A/B)
-static bool pf_for(long workgroups) {
-    const int m = g_osi_tuning.lds_prefetch;
-    return m == 2 || (m == 1 && workgroups <= 7L * hw_cus());
-}
-// "wave_prio": 0 off; 1 every forward / input-gradient launch; 2 only launches whose workgroups are all resident at once
-// (at most 8 per CU), where nothing refills a CU once its oldest workgroups have left
-static int prio_for(long workgroups) {
-    const int m = g_osi_tuning.wave_prio;
-    return m == 1 ? 1 : (m == 2 && workgroups <= 8L * hw_cus()) ? 1 : 0;
-}
 
 // ---- balanced remainder: plan ------------------------------------------------------------------------------------------------
 struct TailPlan { int MT1, S, ksT, tiles; };   // tiles = remainder tiles ((MT - MT1) * NT); S <= 1: no split
@@ -1584,34 +1519,32 @@ static TailPlan plan_tail_split(long MT, int NT, int T) {
 }
 static size_t tail_slab_floats(const TailPlan& t) { return t.S > 1 ? (size_t)t.tiles * t.S * 4096 : 0; }
 
-template <int XF, bool PF = false>
+template <int XF>
 static int launch_fwd_split(ConvP p, const TailPlan& tp, float* slab, hipStream_t st) {
     p.MT = osi_cdiv(p.M, 64); p.NT = p.Cout / 64;
     p.MT1 = tp.MT1; p.ks_S = tp.S; p.ks_T = tp.ksT; p.ks_slab = slab;
     p.g1 = osi_cdiv(p.MT1, 8) * 8 * p.NT;
     const int keys = (p.MT - p.MT1) * tp.S;
     const int grid = p.g1 + osi_cdiv(keys, 8) * 8 * p.NT;
-    p.prio = prio_for((long)p.MT * p.NT);
     size_t smem = (size_t)(64 + 64) * LDR * sizeof(float);
     if (XF) smem += (size_t)2 * p.Cin * sizeof(float);
-    if (int e = set_smem(k_conv_fwd<1, 1, false, 1, XF, true, PF>, smem)) return e;
-    hipLaunchKernelGGL((k_conv_fwd<1, 1, false, 1, XF, true, PF>), dim3(grid), dim3(256), smem, st, p);
+    if (int e = set_smem(k_conv_fwd<1, 1, false, 1, XF, true>, smem)) return e;
+    hipLaunchKernelGGL((k_conv_fwd<1, 1, false, 1, XF, true>), dim3(grid), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_conv_fwd_tail_fixup, dim3(tp.tiles), dim3(256), 0, st, p);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
 
-template <int WM, int WN, bool STEM, int NST = 2, int XF = 0, bool PF = false>
+template <int WM, int WN, bool STEM, int NST = 2, int XF = 0>
 static int launch_fwd(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     p.MT = osi_cdiv(p.M, BM); p.NT = p.Cout / BN;
     size_t smem = NST * (size_t)(BM + BN) * LDR * sizeof(float);
     if (XF) smem += (size_t)2 * p.Cin * sizeof(float);
-    if (int e = set_smem(k_conv_fwd<WM, WN, STEM, NST, XF, false, PF>, smem)) return e;
+    if (int e = set_smem(k_conv_fwd<WM, WN, STEM, NST, XF>, smem)) return e;
     int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
-    p.prio = prio_for((long)p.MT * p.NT * WM * WN);
-    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM, NST, XF, false, PF>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM, NST, XF>), dim3(grid), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
@@ -1632,7 +1565,6 @@ static int launch_dgrad_impl(ConvP p, hipStream_t st) {
     smem = smem / 2 * NST;
     if (int e = set_smem(k_conv_dgrad<WM, WN, NST, FUSED, false, POOL>, smem)) return e;
     int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
-    p.prio = prio_for((long)p.MT * p.NT * s * s * WM * WN);
     hipLaunchKernelGGL((k_conv_dgrad<WM, WN, NST, FUSED, false, POOL>), dim3(grid, s * s), dim3(256), smem, st, p, Hc, Wc);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
@@ -1647,7 +1579,6 @@ static int launch_dgrad_split(ConvP p, const TailPlan& tp, float* slab, hipStrea
     p.g1 = osi_cdiv(p.MT1, 8) * 8 * p.NT;
     const int keys = (p.MT - p.MT1) * tp.S;
     const int grid = p.g1 + osi_cdiv(keys, 8) * 8 * p.NT;
-    p.prio = prio_for((long)p.MT * p.NT);
     const size_t smem = (size_t)(64 * LDR + BK * (64 + 4)) * sizeof(float);
     hipLaunchKernelGGL((k_conv_dgrad<1, 1, 1, FUSED, true>), dim3(grid, 1), dim3(256), smem, st, p, p.H, p.W);
     OSI_LAUNCH_CHECK();
@@ -1919,10 +1850,6 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
         if (tp.S > 1 && pstats_bytes >= (fwd_stats_floats(d) + tail_slab_floats(tp)) * sizeof(float)) {
             if (int e = with_stats(64)) return e;
             float* slab = pstats + fwd_stats_floats(d);
-            if (pf_for((long)osi_cdiv(p.M, 64) * (d->Cout / 64))) {
-                if (in_scale) return res ? launch_fwd_split<2, true>(p, tp, slab, st) : launch_fwd_split<1, true>(p, tp, slab, st);
-                return launch_fwd_split<0, true>(p, tp, slab, st);
-            }
             if (in_scale) return res ? launch_fwd_split<2>(p, tp, slab, st) : launch_fwd_split<1>(p, tp, slab, st);
             return launch_fwd_split<0>(p, tp, slab, st);
         }
@@ -1939,9 +1866,7 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
         if (g_osi_tuning.fwd_wide && d->Cout % 128 == 0) tile = OSI_TILE_64x128_S1;   // A/B: wide tiles wherever the channel count allows
     }
     if (int e = with_stats(fwd_tile_rows(tile))) return e;
-    const bool pf = tile == OSI_TILE_64x64_S1 && pf_for((long)osi_cdiv(p.M, 64) * (d->Cout / 64));
     if (in_scale) {   // fused input activation: built for the single-buffered 64-row tiles the executor uses
-        if (pf) return res ? launch_fwd<1, 1, false, 1, 2, true>(p, st) : launch_fwd<1, 1, false, 1, 1, true>(p, st);
         if (tile == OSI_TILE_64x64_S1) return res ? launch_fwd<1, 1, false, 1, 2>(p, st) : launch_fwd<1, 1, false, 1, 1>(p, st);
         if (tile == OSI_TILE_64x128_S1) {
             OSI_REQUIRE(d->Cout % 128 == 0);
@@ -1954,7 +1879,7 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
         case OSI_TILE_128x64: return launch_fwd<2, 1, false>(p, st);
         case OSI_TILE_64x128: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<1, 2, false>(p, st);
         case OSI_TILE_64x64: return launch_fwd<1, 1, false>(p, st);
-        case OSI_TILE_64x64_S1: return pf ? launch_fwd<1, 1, false, 1, 0, true>(p, st) : launch_fwd<1, 1, false, 1>(p, st);
+        case OSI_TILE_64x64_S1: return launch_fwd<1, 1, false, 1>(p, st);
         case OSI_TILE_64x128_S1: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<1, 2, false, 1>(p, st);
         case OSI_TILE_128x128_S1: OSI_REQUIRE(d->Cout % 128 == 0); return launch_fwd<2, 2, false, 1>(p, st);
         case OSI_TILE_128x64_S1: return launch_fwd<2, 1, false, 1>(p, st);

@@ -40,8 +40,6 @@ struct OsiTuning {
     int tail_qmax;      // ... and most full rounds a launch may have
     int bn_grid_bwd;    // grid cap of the BatchNorm BACKWARD apply kernels (they run beside the weight gradients)
     int bn_wide_p;      // BatchNorm finalisation (forward statistics and backward sums): ONE 1024-thread launch up to this many partials
-    int wave_prio;        // fwd / dgrad: wave priority by progress through the K loop: 0 off, 1 every launch, 2 single-round launches only
-    int lds_prefetch;     // fwd: operand fragments prefetched one sub-step ahead (7 waves / SIMD): 0 off, 1 launches of <= 7 workgroups per CU, 2 always
     int dp_reserved_cus;  // CUs' worth of wave slots the launch plans leave to co-resident communication kernels (data parallel); 0 = none
 };
 extern OsiTuning g_osi_tuning;

@@ -49,6 +49,11 @@ struct Block {
 };
 
 constexpr size_t ALIGN_F = 64;  // floats (256 B)
+// The executor's events only order streams of ONE device against each other (fork / join of the weight-gradient side stream, reader
+// events of the scratch buffers, the data-parallel hand-off). By default a HIP event performs a SYSTEM-scope fence when it is recorded
+// — a cache writeback + invalidate that makes device memory visible to the host and to other devices — which none of them needs: the
+// kernels on both sides carry their own agent-scope acquire / release. ~115 records per step.
+constexpr unsigned EV_FLAGS = hipEventDisableTiming | hipEventDisableSystemFence;
 static size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -190,11 +195,11 @@ struct osi_resnet50 {
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return OSI_ERR_LAUNCH;
         const int prio = side_prio_normal ? 0 : lo;   // option "side_priority_normal": default priority for the side stream (A/B)
         if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio) != hipSuccess) return OSI_ERR_LAUNCH;
-        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
-        if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
-        if (hipEventCreateWithFlags(&ev_wdone, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&ev_fork, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&ev_join, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&ev_wdone, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
         for (int i = 0; i < NSCR; ++i)
-            if (hipEventCreateWithFlags(&buf_ev[i], hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
+            if (hipEventCreateWithFlags(&buf_ev[i], EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
         return OSI_OK;
     }
     bool async_wgrad() const { return overlap && (!prof_on || prof_timeline) && side != nullptr; }
@@ -900,8 +905,8 @@ int osi_resnet50_grads_ready(osi_resnet50_t n, osi_stream_t main_stream, osi_str
     OSI_REQUIRE(n);
     hipStream_t mn = (hipStream_t)main_stream, wt = (hipStream_t)waiter_stream;
     if (!n->ev_rmain) {
-        if (hipEventCreateWithFlags(&n->ev_rmain, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
-        if (hipEventCreateWithFlags(&n->ev_rside, hipEventDisableTiming) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&n->ev_rmain, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&n->ev_rside, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
     }
     if (hipEventRecord(n->ev_rmain, mn) != hipSuccess) return OSI_ERR_LAUNCH;
     if (hipStreamWaitEvent(wt, n->ev_rmain, 0) != hipSuccess) return OSI_ERR_LAUNCH;

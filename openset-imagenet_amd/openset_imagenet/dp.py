@@ -16,6 +16,8 @@ Design for point-to-point xGMI (7 links x ~153 GB/s per GPU, no switch):
     collectives before the optimizer step.
 On gloo (CPU tests) the same code averages with SUM + divide; on nccl (= RCCL) it uses ReduceOp.AVG in place.
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -50,7 +52,10 @@ class GradSync:
 
     def _comm(self, device):
         if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=device)
+            # high priority: its own hardware queue set (the compute stream is normal, the weight-gradient side stream low priority). On a
+            # queue shared with the compute stream, this stream's wait for the side stream would hold back the compute stream's next kernels
+            prio = int(os.environ.get("OSI_DP_COMM_PRIO", "-1"))
+            self._comm_stream = torch.cuda.Stream(device=device, priority=prio)
         return self._comm_stream
 
     def bucket_ready(self, flat, lo, hi, handoff=None):

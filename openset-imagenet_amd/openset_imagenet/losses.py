@@ -49,6 +49,39 @@ class _FusedLoss(torch.autograd.Function):
         return gl, None, gf, None
 
 
+class _LossValue(torch.Tensor):
+    """The 0-dim loss a fused loss returns when its logits come straight from the MI355X ResNet50. It is an ordinary tensor
+    (`.item()`, arithmetic, autograd all work); only the plain `j.backward()` of the reference loop (train.py:138) is special:
+    dJ/dlogits (and dJ/dfeatures) — already computed by the loss kernel — go straight to the network's backward instead of
+    through autograd's seed gradient (a ones_like fill) and a `dlogits * 1` multiply: two elementwise launches fewer between the
+    forward and the backward pass. Every other use (gradient=, inputs=, retain_graph, create_graph, or a loss that was combined
+    with other terms and therefore is a new tensor) takes the ordinary autograd route, which gives the same gradients."""
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        direct = self.__dict__.pop("_osi_direct", None)
+        if direct is None or gradient is not None or retain_graph or create_graph or inputs is not None:
+            return super().backward(gradient, retain_graph, create_graph, inputs)
+        node, fn = direct
+        model = node.model
+        if node.serial != model._fwd_serial:
+            raise RuntimeError("backward() of a forward pass that is no longer the model's latest one: the executor keeps the "
+                               "activations of ONE forward (the reference loop is forward, loss, backward, step — train.py:132-139)")
+        dlogits, dfeat = fn.saved_tensors
+        model._run_backward(dlogits if dlogits.numel() else None, dfeat if (fn.has_feat and dfeat.numel()) else None)
+
+
+def _loss_value(j, logits, features=None):
+    """Wrap the loss for the direct backward when `logits` (and `features`) are the two outputs of one ResNet50 forward."""
+    node = logits.grad_fn
+    if not j.requires_grad or node is None or getattr(node, "model", None) is None or not hasattr(node, "serial"):
+        return j
+    if features is not None and features.grad_fn is not node:
+        return j
+    out = j.as_subclass(_LossValue)
+    out._osi_direct = (node, j.grad_fn)
+    return out
+
+
 class EntropicOpensetLoss:
     """Entropic open-set loss (reference losses.py:7-29): one-hot targets for y >= 0, w/C for every negative label,
     mean over all rows of the batch."""
@@ -61,7 +94,7 @@ class EntropicOpensetLoss:
     def __call__(self, logits, target):
         if logits.shape[1] != self.class_count:
             raise ValueError(f"logits have {logits.shape[1]} classes, loss was built for {self.class_count}")
-        return _FusedLoss.apply(logits, target, None, (N.LOSS_ENTROPIC, self.unk_weight, -1, None, 0.0, 0.0))
+        return _loss_value(_FusedLoss.apply(logits, target, None, (N.LOSS_ENTROPIC, self.unk_weight, -1, None, 0.0, 0.0)), logits)
 
 
 class SoftmaxLoss:
@@ -71,7 +104,7 @@ class SoftmaxLoss:
         self.ignore_index = int(ignore_index)
 
     def __call__(self, logits, target):
-        return _FusedLoss.apply(logits, target, None, (N.LOSS_SOFTMAX, 1.0, self.ignore_index, None, 0.0, 0.0))
+        return _loss_value(_FusedLoss.apply(logits, target, None, (N.LOSS_SOFTMAX, 1.0, self.ignore_index, None, 0.0, 0.0)), logits)
 
 
 class GarbageLoss:
@@ -85,7 +118,7 @@ class GarbageLoss:
             self.weight = self.weight.to(logits.device)
         if self.weight.numel() != logits.shape[1]:
             raise ValueError("class_weights length must equal the number of logits")
-        return _FusedLoss.apply(logits, target, None, (N.LOSS_GARBAGE, 1.0, -100, self.weight, 0.0, 0.0))
+        return _loss_value(_FusedLoss.apply(logits, target, None, (N.LOSS_GARBAGE, 1.0, -100, self.weight, 0.0, 0.0)), logits)
 
 
 class ObjectosphereLoss:
@@ -96,8 +129,8 @@ class ObjectosphereLoss:
         self.unk_weight, self.xi, self.alpha = float(unk_weight), float(xi), float(alpha)
 
     def __call__(self, logits, target, features):
-        return _FusedLoss.apply(logits, target, features,
-                                (N.LOSS_ENTROPIC, self.unk_weight, -1, None, self.xi, self.alpha))
+        return _loss_value(_FusedLoss.apply(logits, target, features,
+                                            (N.LOSS_ENTROPIC, self.unk_weight, -1, None, self.xi, self.alpha)), logits, features)
 
 
 def softmax(logits):

@@ -331,8 +331,9 @@ def _worker_body(cfg, log, out_dir, rank, world, distributed):
             try:
                 validate(model, val_loader, loss_fn, n_classes, v_metrics, cfg)
                 curr_score = v_metrics["conf_kn"].avg + v_metrics["conf_unk"].avg
-            except BaseException as e:                    # the other ranks wait in the broadcast below: tell them before re-raising
-                failure = e
+            except Exception as e:                        # the other ranks wait in the broadcast below: tell them before re-raising.
+                failure = e                               # (KeyboardInterrupt / SystemExit propagate at once: the launcher ends the ranks)
+                log.exception("rank 0 failed in validate()")   # the original traceback, before any collective can mask it
         # learning-rate schedule: stepped on every rank, after validation and BEFORE the checkpoints are written (reference
         # train.py:435-437 then :463-471), so that `_curr.pth` / `_best.pth` carry the scheduler state and learning rate of the epoch
         # they resume into
@@ -352,8 +353,9 @@ def _worker_body(cfg, log, out_dir, rank, world, distributed):
                 if early is not None:
                     early(metrics=curr_score, loss=False)
                     stop = early.early_stop
-            except BaseException as e:
+            except Exception as e:
                 failure = e
+                log.exception("rank 0 failed while logging / writing checkpoints")
         if distributed:                                   # every rank follows rank 0's early-stopping decision — or its failure
             flag = [stop, best_score, None if failure is None else repr(failure)]
             dist.broadcast_object_list(flag, src=0)

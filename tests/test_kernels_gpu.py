@@ -588,3 +588,40 @@ def test_dgrad_fused_epilogue_vs_unfused(cuda, Cin, Cout, k, stride, H, B, two):
             assert float((dyo - rdy).abs().max()) <= 2e-5 * scale, f"dy consumer {j} wide_p {wide_p}"
             assert float((dg - rdg).abs().max()) <= 2e-5 * (float(rdg.abs().max()) + 1e-30), f"dgamma consumer {j} wide_p {wide_p}"
             assert float((db - rdb).abs().max()) <= 2e-5 * (float(rdb.abs().max()) + 1e-30), f"dbeta consumer {j} wide_p {wide_p}"
+
+
+@pytest.mark.parametrize("P,C", [(392, 256), (1568, 128), (6272, 64), (98, 512)])
+def test_bn_merge_with_large_mean_and_outlier_first_tile(cuda, P, C):
+    """The one-pass merges of the conv-epilogue partials (k_bn_stats_final_wide, k_bn_stats_group) subtract S1^2 / M from S2: that
+    only works while the pivot of the shifted sums is near the batch mean. Hard case: |mean| / sigma = 1e4 and a FIRST tile (the
+    top-left corner of image 0: border pixels) 50 sigma away from everything else. Every finalisation form (one 256-thread
+    launch, one 1024-thread launch, two levels) against fp64."""
+    from openset_imagenet import _native as N
+    import osi_testlib as T
+    L = N.lib()
+    g = torch.Generator().manual_seed(P + C)
+    rows, M = 64, P * 64 - 17
+    mu, sigma = 100.0, 0.01
+    y = (mu + sigma * torch.randn(M, C, generator=g, dtype=torch.float64))
+    y[:rows] += 50 * sigma
+    y = y.float().double()                                   # the values the conv would have produced (fp32)
+    pad = torch.cat([y, torch.full((P * rows - M, C), float("nan"), dtype=torch.float64)])
+    tiles = pad.view(P, rows, C)
+    pm = torch.nanmean(tiles, dim=1)
+    pq = torch.nansum((tiles - pm[:, None]) ** 2, dim=1)
+    rmean = y.mean(0); rM2 = ((y - rmean) ** 2).sum(0)
+    gamma, beta = torch.ones(C, device=cuda), torch.zeros(C, device=cuda)
+    for single_p, wide_p in ((128, 2048), (1, 2048), (1, 0)):
+        N.check(L.osi_set_tuning(b"bn_single_p", single_p)); N.check(L.osi_set_tuning(b"bn_wide_p", wide_p))
+        try:
+            nb = max(L.osi_bn_workspace(M, C), 2 * P * C * 4 + 2 * 32 * C * 4 + 1024)
+            ps = torch.zeros(nb // 4, device=cuda)
+            ps[:P * C] = pm.float().flatten().to(cuda); ps[P * C:2 * P * C] = pq.float().flatten().to(cuda)
+            o = [torch.empty(C, device=cuda) for _ in range(4)]
+            N.check(L.osi_bn_finalize_stats(N.ptr(ps), nb, P, rows, M, C, N.ptr(gamma), N.ptr(beta), 1e-5, 0.1, None, None,
+                                            *[N.ptr(t) for t in o], T.S()), "osi_bn_finalize_stats")
+        finally:
+            N.check(L.osi_set_tuning(b"bn_single_p", 128)); N.check(L.osi_set_tuning(b"bn_wide_p", 2048))
+        inv = 1 / torch.sqrt(rM2 / M + 1e-5)
+        assert float((o[0].cpu().double() - rmean).abs().max()) <= 5e-5, (single_p, wide_p)           # |mean| = 100: 6 ulp of fp32
+        assert float((o[1].cpu().double() / inv - 1).abs().max()) <= 2e-4, (single_p, wide_p, float((o[1].cpu().double() / inv - 1).abs().max()))
