@@ -148,7 +148,7 @@ def test_torch_op_library_registers_without_a_gpu():
         assert hasattr(ops, name), name
     with pytest.raises(NotImplementedError):
         ops.softmax(torch.zeros(2, 3))
-    assert N.lib().osi_abi_version() >= 4
+    assert N.lib().osi_abi_version() >= 5
 
 
 def test_tuning_knobs_are_explicit():
