@@ -1,3 +1,7 @@
+#!/bin/bash
+# Same box, interleaved (round 4): does the data-parallel hand-off's cost come from hardware-queue aliasing? handoff = staged backward +
+# osi_resnet50_grads_ready, RCCL's all_reduce patched out; dp = with it. "hi" / "normal" = priority of the communication stream
+# (OSI_DP_COMM_PRIO), "q8" = GPU_MAX_HW_QUEUES=8. Result: profiles/r04_ab_dp_queues.txt
 for r in 1 2; do
 for cfg in plain "handoff hi" "handoff normal" "handoff hi q8" "dp hi" "dp normal" "dp hi q8"; do
   set -- $cfg
