@@ -23,6 +23,13 @@ for p in (ROOT, os.path.join(ROOT, "openset-imagenet_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# RCCL has no API for its channel count (= the workgroups a collective keeps resident on this GPU): rank 0 reads it from the
+# communicator's own INIT log, written to a private file (stdout stays one JSON line). Set before torch loads RCCL.
+RCCL_LOG = None
+if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-dp" in sys.argv) and os.environ.get("RANK", "0") == "0" \
+        and os.environ.get("OSI_BENCH_BACKEND", "nccl") == "nccl" and "NCCL_DEBUG" not in os.environ:
+    RCCL_LOG = f"/tmp/osi_rccl_init_{os.getpid()}.log"
+    os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_FILE=RCCL_LOG)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -238,10 +245,13 @@ def rccl_channels(path):
     import re
     info = {"NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"), "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
             "coll_channels": None, "source": None}
-    try:
-        txt = open(path, errors="replace").read() if path else ""
-    except OSError:
-        txt = ""
+    import glob
+    txt = ""
+    for f in (sorted(glob.glob(path + "*")) if path else []):      # RCCL may append host / pid suffixes to NCCL_DEBUG_FILE
+        try:
+            txt += open(f, errors="replace").read()
+        except OSError:
+            pass
     m = re.findall(r"(\d+) coll channels", txt)
     if m:
         info.update(coll_channels=int(m[-1]), source='"N coll channels" line of the NCCL_DEBUG=INFO init log')
@@ -291,15 +301,10 @@ def main():
         local %= max(1, torch.cuda.device_count())
     dev = tools.set_device_gpu(local)
     use_dp = world > 1 or args.force_dp
-    rccl_log = None
+    rccl_log = RCCL_LOG
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        if backend == "nccl" and rank == 0 and "NCCL_DEBUG" not in os.environ:
-            # RCCL has no API for its channel count (= the workgroups a collective keeps resident on this GPU): read it from the
-            # communicator's own INIT log, written to a private file (stdout stays one JSON line)
-            rccl_log = f"/tmp/osi_rccl_init_{os.getpid()}.log"
-            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_FILE=rccl_log)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
