@@ -282,3 +282,26 @@ def test_imagenet_dataset_has_the_reference_constructor_and_members(tmp_path):
     ds2 = oi.ImagenetDataset(tmp_path / "d.csv", tmp_path)
     ds2.remove_negative_label()
     assert len(ds2) == 15 and ds2.label_count == 3 and list(ds2.unique_classes) == [0, 1, 2] and int(ds2[0][1]) == 0
+
+
+def test_bench_record_helpers(tmp_path):
+    """bench.py's host-side helpers for the N > 1 record: RCCL's channel count parsed from its own INIT log (both line forms, the last
+    communicator wins, suffixed log files are found), the CPU share of a lease (x the GPUs THIS RUN uses, never the visible count),
+    the CPU model string."""
+    import importlib.util
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    spec = importlib.util.spec_from_file_location("osi_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    log = tmp_path / "rccl.log"
+    (tmp_path / "rccl.log.host.123").write_text("x:1:2 [0] NCCL INFO Channel 00/128 : 0\nx:1:2 [0] NCCL INFO Channel 01/128 : 0\n")
+    info = bench.rccl_channels(str(log))
+    assert info["coll_channels"] == 128 and "Channel" in info["source"]
+    log.write_text("h:9:9 [0] NCCL INFO 16 coll channels, 16 collnet channels, 0 nvls channels, 32 p2p channels\n"
+                   "h:9:9 [0] NCCL INFO 32 coll channels, 32 collnet channels, 0 nvls channels, 32 p2p channels, 2 p2p channels per peer\n")
+    assert bench.rccl_channels(str(log))["coll_channels"] == 32
+    assert bench.rccl_channels(None)["coll_channels"] is None and bench.rccl_channels(str(tmp_path / "missing"))["coll_channels"] is None
+    one, eight = bench.usable_cpus(1, 16), bench.usable_cpus(8, 16)
+    assert one["lease_share"] == 16 and eight["lease_share"] == 128 and one["threads"] <= 16 and 1 <= one["threads"] <= eight["threads"]
+    assert bench.usable_cpus(1, 2)["threads"] <= 2
+    assert isinstance(bench.cpu_model(), str) and bench.cpu_model()
