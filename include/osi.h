@@ -46,6 +46,8 @@ const char* osi_strerror(int code);
  *   wgrad3 *         0 .. 2        2        all-taps 3x3 weight-gradient kernel: 0 never, 1 stride-1 layers, 2 stride-2 layers too
  *   wgrad3_blocks *  1 .. 2^20     768      workgroups per launch its split-K plan aims for
  *   fwd_wide         0 | 1         0        A/B: 64x128 forward tiles wherever Cout % 128 == 0
+ *   fwd_rows         0 .. 2        1        1x1 stride-1 forward convolutions with Cin = 64 on the persistent row walker (weight tile resident in LDS,
+ *                                           next row tile prefetched) when the launch has >= 8 row tiles per CU; 2 = every eligible shape (Cin = 64 | 128)
  *   dgrad_wide       0 | 1         0        A/B: 64x128 input-gradient tiles wherever Cin % 128 == 0
  *   bn_grid          1 .. 2^20     1024     grid cap of the BatchNorm stream kernels
  *   bn_grid_bwd      1 .. 2^20     1024     the same for the backward apply kernels

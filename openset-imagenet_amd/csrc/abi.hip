@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1, /*tail_gain*/ 8, /*tail_qmax*/ 8, /*bn_grid_bwd*/ 1024, /*bn_wide_p*/ 2048, /*dp_reserved_cus*/ 0};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1, /*tail_gain*/ 8, /*tail_qmax*/ 8, /*bn_grid_bwd*/ 1024, /*bn_wide_p*/ 2048, /*fwd_rows*/ 1, /*dp_reserved_cus*/ 0};
 
 namespace {
 int* tuning_slot(const char* name) {
@@ -28,6 +28,7 @@ int* tuning_slot(const char* name) {
     if (!strcmp(name, "tail_gain")) return &g_osi_tuning.tail_gain;
     if (!strcmp(name, "tail_qmax")) return &g_osi_tuning.tail_qmax;
     if (!strcmp(name, "dp_reserved_cus")) return &g_osi_tuning.dp_reserved_cus;
+    if (!strcmp(name, "fwd_rows")) return &g_osi_tuning.fwd_rows;
     return nullptr;
 }
 }  // namespace
@@ -55,6 +56,7 @@ int osi_set_tuning(const char* name, int value) {
     else if (s == &t.tail_gain) good = in(0, 100);
     else if (s == &t.tail_qmax) good = in(0, 4096);
     else if (s == &t.dp_reserved_cus) good = in(0, 128);
+    else if (s == &t.fwd_rows) good = in(0, 2);
     if (!good) return OSI_ERR_ARG;
     *s = value;
     return OSI_OK;

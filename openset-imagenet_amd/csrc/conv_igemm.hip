@@ -1324,6 +1324,143 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
     OSI_STAMP(p, blockIdx.x, 3);
 }
 
+// ======================================================================================================
+// Forward, 1x1 stride-1 convolutions with a SHORT K (Cin = 64 or 128): persistent row walker.
+// With K = 64 a 64x64 tile is two K tiles = 32 MFMAs per wave between a prologue (row addresses, first operand round trip) and an
+// epilogue (LDS transpose, 16 KB of output, BatchNorm partials): tools/wg_timeline.py shows a k_conv_fwd workgroup of 64->256 @56x56
+// spending 27 % of its life in its K loop (prologue 4.4 + loop 3.3 + epilogue 4.2 us, 98 workgroups per CU): the layer is bound by
+// those two latencies and by 514 MB of HBM traffic, not by the matrix pipe. Here a workgroup owns ONE column tile, keeps its weight tile
+// (all of K) in LDS for its whole life, and walks row tiles mt = walker, walker + walkers, ...: the next tile's activation rows are
+// fetched into registers BEFORE the MFMAs and the epilogue of the current one, so the load round trip hides behind them and no
+// per-tile prologue is left. The four (Cout / 64) workgroups of a walker take consecutive dispatch slots of one XCD: they stream the
+// same rows at about the same time and three of four reads hit that L2. Epilogue as in k_conv_fwd (LDS transpose -> 16-byte
+// stores, BatchNorm (mean, M2) partials per row tile straight from the accumulators).
+// ======================================================================================================
+template <int KT, int XF>   // KT = Cin / 32 K tiles (2 or 4); XF = 1: the A operand is relu(x * in_scale[c] + in_shift[c])
+__global__ __launch_bounds__(256, 4) void k_conv1x1_rows(ConvP p, int walkers) {
+    constexpr int BN = 64, IMG = 64 * LDR, LDT = BN + 4;
+    static_assert(64 * LDT <= KT * IMG, "the transposed output tile reuses the activation images");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sB = smem;                    // [KT][64][LDR] the column tile's weights, resident
+    float* sA = smem + KT * IMG;         // [KT][64][LDR] the current row tile; reused as the transposed output tile
+    float* s_sc = sA + KT * IMG;         // XF: [Cin] scale | [Cin] shift
+    float* s_sh = s_sc + p.Cin;
+    float* s_st = s_sh + p.Cin;          // [2][64][3] statistics of the two wave rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int kq = tid & 7, lr = tid >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nt = slot % p.NT, walker = (slot / p.NT) * 8 + xcd;
+    if (walker >= walkers) return;
+    const int n0 = nt * BN;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.w, p.w_bytes);
+    {   // the weight tile: rows n0 + lr (+ 32), all of K
+        f32x4 rb[KT][2];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rb[kt][i] = bld4(rw, ((uint32_t)(n0 + lr + 32 * i) * p.Ktot + kq * 4) * 4, (uint32_t)(kt * BK * 4));
+        if (XF) {
+            for (int c = tid * 4; c < p.Cin; c += 1024) {
+                *reinterpret_cast<f32x4*>(s_sc + c) = ld4(p.in_scale + c);
+                *reinterpret_cast<f32x4*>(s_sh + c) = ld4(p.in_shift + c);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(sB + kt * IMG + (lr + 32 * i) * LDR + kq * 4) = rb[kt][i];
+    }
+    f32x4 ra[KT][2];
+    bool rok[2] = {false, false};
+    auto gloadA = [&](int mt) {          // row tile mt -> registers; rows past M read as zeros (range check)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mt * 64 + lr + 32 * i;
+            rok[i] = m < p.M;
+            const uint32_t off = rok[i] ? ((uint32_t)m * p.Cin + kq * 4) * 4 : OOB;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) ra[kt][i] = bld4(rx, off, (uint32_t)(kt * BK * 4));
+        }
+    };
+    auto sstoreA = [&]() {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 sc = {0, 0, 0, 0}, sh = sc;
+            if (XF) { sc = *reinterpret_cast<const f32x4*>(s_sc + kt * BK + kq * 4); sh = *reinterpret_cast<const f32x4*>(s_sh + kt * BK + kq * 4); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 v = ra[kt][i];
+                if (XF) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], sc[e], sh[e]), 0.f);
+                    v = rok[i] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                *reinterpret_cast<f32x4*>(sA + kt * IMG + (lr + 32 * i) * LDR + kq * 4) = v;
+            }
+        }
+    };
+    int mt = walker;
+    gloadA(mt);
+    if (XF) __syncthreads();             // the scale / shift tables are complete
+    sstoreA();
+    while (mt < p.MT) {
+        __syncthreads();                 // the row tile (and, the first time, the weight tile) is visible
+        const int mt_next = mt + walkers;
+        if (mt_next < p.MT) gloadA(mt_next);      // in flight behind the MFMAs and the epilogue below
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) mma_RR<1, 1>(sA + kt * IMG, sB + kt * IMG, wm * 32, wn * 32, lane, acc);
+        __syncthreads();                 // every wave is done reading the row tile: its LDS becomes the transposed output tile
+        const int m0 = mt * 64;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) sA[(wm * 32 + acc_row(rr, lane)) * LDT + wn * 32 + (lane & 31)] = acc[0][0][rr];
+        __syncthreads();
+        {   // 16-byte stores of 4 consecutive channels per lane (measured against 4-byte stores straight from the accumulators, which
+            // save two barriers per tile: 86 vs 82 TFLOP/s on 64->256 @56x56)
+            const int c4 = tid & 15, rg = tid >> 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rl = rg + 16 * k, m = m0 + rl;
+                if (m < p.M)
+                    *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + c4 * 4) = *reinterpret_cast<const f32x4*>(sA + rl * LDT + c4 * 4);
+            }
+        }
+        if (p.pmean) {                   // BatchNorm (mean, M2) partials of this row tile's 64 columns (see k_conv_fwd)
+            const int row0 = m0 + wm * 32;
+            const float cnt = (float)min(32, max(0, p.M - row0));
+            float sm = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) sm += (row0 + acc_row(rr, lane) < p.M) ? acc[0][0][rr] : 0.f;
+            sm += __shfl_xor(sm, 32, 64);
+            const float mu = cnt > 0.f ? sm / cnt : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const float dlt = acc[0][0][rr] - mu;
+                q += (row0 + acc_row(rr, lane) < p.M) ? dlt * dlt : 0.f;
+            }
+            q += __shfl_xor(q, 32, 64);
+            if (lane < 32) {
+                float* dst = s_st + (wm * BN + wn * 32 + lane) * 3;
+                dst[0] = cnt; dst[1] = mu; dst[2] = q;
+            }
+        }
+        __syncthreads();                 // transposed tile read, statistics of both wave rows written
+        if (p.pmean && tid < BN) {
+            const float* a = s_st + tid * 3;
+            const float* b = s_st + (BN + tid) * 3;
+            float cn = a[0], cm = a[1], cs = a[2];
+            chan_merge(cn, cm, cs, b[0], b[1], b[2]);
+            p.pmean[(size_t)mt * p.Cout + n0 + tid] = cm;
+            p.pm2[(size_t)mt * p.Cout + n0 + tid] = cs;
+        }
+        if (mt_next < p.MT) sstoreA();   // (s_st is rewritten only behind the next tile's barriers, which its readers reach after reading)
+        mt = mt_next;
+    }
+}
+
 // Fix-up pass of a forward launch with a K-split tail (tile_of_block_split): one workgroup per remainder tile adds the tile's
 // splits in split order (fixed: bitwise reproducible), writes the output rows and — like the convolution's own epilogue — the
 // BatchNorm partial (mean, M2) of the tile's 64 columns over its valid rows (two passes over the register-resident tile).
@@ -1548,6 +1685,27 @@ static int launch_fwd(ConvP p, hipStream_t st) {
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
+// 1x1 stride-1 forward with Cin = 64 / 128 on the persistent row walker (k_conv1x1_rows): four resident workgroups per CU
+template <int KT, int XF>
+static int launch_fwd_rows(ConvP p, hipStream_t st) {
+    p.MT = osi_cdiv(p.M, 64); p.NT = p.Cout / 64;
+    int walkers = (4 * hw_cus() / p.NT + 7) / 8 * 8;
+    if (walkers < 8) walkers = 8;
+    if (walkers > p.MT) walkers = (p.MT + 7) / 8 * 8;
+    const size_t smem = ((size_t)2 * KT * 64 * LDR + 2 * p.Cin + 2 * 64 * 3) * sizeof(float);
+    if (int e = set_smem(k_conv1x1_rows<KT, XF>, smem)) return e;
+    hipLaunchKernelGGL((k_conv1x1_rows<KT, XF>), dim3(walkers * p.NT), dim3(256), smem, st, p, walkers);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+// "fwd_rows": 0 off; 1 (default) Cin = 64 and at least eight row tiles per CU (the 56 x 56 layers of layer1 at batch >= 42: 64->256
+// 78 -> 86 TFLOP/s, 64->64 76.5 -> 79.9; Cin = 128 @28x28 measured 102.5 -> 100.5: stays on k_conv_fwd); 2 every shape the kernel takes (tests)
+static bool rows_rule(const osi_conv_desc* d, bool unit, const float* res) {
+    const int m = g_osi_tuning.fwd_rows;
+    if (!m || !unit || res || d->Cout % 64 || (d->Cin != 64 && d->Cin != 128)) return false;
+    return m == 2 || (d->Cin == 64 && (long)d->B * d->Ho * d->Wo >= 64L * 8 * hw_cus());
+}
+
 template <int WM, int WN, int NST, int FUSED, bool POOL = false>
 static int launch_dgrad_impl(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -1844,6 +2002,11 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
         return launch_fwd<2, 1, true>(p, st);
     }
     OSI_REQUIRE(d->Cin % BK == 0 && d->Cout % 64 == 0);
+    if (tile == OSI_TILE_AUTO && rows_rule(d, p.unit != 0, res)) {      // short-K 1x1 layers: persistent row walker
+        if (int e = with_stats(64)) return e;
+        if (d->Cin == 64) return in_scale ? launch_fwd_rows<2, 1>(p, st) : launch_fwd_rows<2, 0>(p, st);
+        return in_scale ? launch_fwd_rows<4, 1>(p, st) : launch_fwd_rows<4, 0>(p, st);
+    }
     if (tile == OSI_TILE_AUTO && pstats) {
         // ragged last round split along K (plan_tail_split) when the caller's workspace has room for the slab behind the statistics
         const TailPlan tp = fwd_tail_plan(d);

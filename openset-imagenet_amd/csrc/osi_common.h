@@ -40,6 +40,7 @@ struct OsiTuning {
     int tail_qmax;      // ... and most full rounds a launch may have
     int bn_grid_bwd;    // grid cap of the BatchNorm BACKWARD apply kernels (they run beside the weight gradients)
     int bn_wide_p;      // BatchNorm finalisation (forward statistics and backward sums): ONE 1024-thread launch up to this many partials
+    int fwd_rows;         // fwd: 1x1 stride-1 convolutions with Cin = 64 / 128 on the persistent row walker (k_conv1x1_rows): 0 off, 1 Cin = 64 at >= 8 row tiles per CU, 2 every eligible shape (tests)
     int dp_reserved_cus;  // CUs' worth of wave slots the launch plans leave to co-resident communication kernels (data parallel); 0 = none
 };
 extern OsiTuning g_osi_tuning;

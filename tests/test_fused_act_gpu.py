@@ -282,3 +282,55 @@ def test_all_taps_3x3_stride2_weight_gradient(cuda, Cin, Cout, H, W, B, fused):
     assert torch.isfinite(a).all() and torch.equal(a, a2)
     assert float((a.double() - ref).abs().max()) <= (2e-6 + 6e-8 * Kp ** 0.5) * scale + 1e-6
     assert per_tap is None or float((a - per_tap).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("Cin,Cout,H,B", [(64, 64, 14, 3), (64, 256, 9, 3), (128, 512, 7, 5), (128, 64, 20, 2), (64, 128, 1, 70)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_persistent_row_walker_for_short_k_1x1(cuda, Cin, Cout, H, B, fused):
+    """k_conv1x1_rows (1x1 stride-1 convolutions with Cin = 64 / 128: one workgroup keeps its weight tile in LDS and walks row tiles,
+    the next tile's rows prefetched behind the current tile's MFMAs and epilogue) against fp64 and against k_conv_fwd, which it must
+    reproduce BIT FOR BIT (same K order per tile, same statistics arithmetic): ragged last tile, more walkers than row tiles, with and
+    without the fused input activation, with and without statistics. osi_set_tuning("fwd_rows", 2) takes every eligible shape; the
+    default (1) only the 56 x 56 layers of layer1 at production batch sizes (tests/test_production_shapes_gpu.py)."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(Cin + Cout + H + B)
+    x = (torch.randn(B, H, H, Cin, generator=g) * 1.3 + 0.2).to(cuda)
+    w = (torch.randn(Cout, 1, 1, Cin, generator=g) / Cin ** 0.5).to(cuda)
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).to(cuda), (torch.randn(Cin, generator=g) * 0.5).to(cuda)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, 1, 1, 0)
+    M = B * H * H
+    nb = L.osi_conv_fwd_bnstats_workspace(ctypes.byref(d))
+
+    def run(stats):
+        y = torch.full((B, H, H, Cout), float("nan"), device=cuda)
+        ps = torch.full((nb // 4,), float("nan"), device=cuda)
+        P, rows = ctypes.c_int(), ctypes.c_int()
+        pa = (N.ptr(ps), nb, ctypes.byref(P), ctypes.byref(rows)) if stats else (None, 0, None, None)
+        if fused:
+            N.check(L.osi_conv_fwd_act(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(w), N.ptr(y), 0, *pa, T.S()))
+        elif stats:
+            N.check(L.osi_conv_fwd_bnstats(ctypes.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), 0, *pa, T.S()))
+        else:
+            N.check(L.osi_conv_fwd(ctypes.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), 0, T.S()))
+        return y, (ps[:2 * P.value * Cout].clone() if stats else None), (P.value, rows.value)
+
+    v = ctypes.c_int()
+    assert L.osi_get_tuning(b"fwd_rows", ctypes.byref(v)) == 0 and v.value == 1
+    N.check(L.osi_set_tuning(b"tail_split", 0))          # the reference launch: k_conv_fwd, one pass (a K-split tail sums in another order)
+    N.check(L.osi_set_tuning(b"fwd_rows", 0))
+    try:
+        y0, p0, g0 = run(True)
+        N.check(L.osi_set_tuning(b"fwd_rows", 2))
+        y1, p1, g1 = run(True)
+        y2, _, _ = run(False)
+        y3, p3, _ = run(True)
+    finally:
+        N.check(L.osi_set_tuning(b"fwd_rows", 1)); N.check(L.osi_set_tuning(b"tail_split", 1))
+    a64 = torch.relu(x.double() * sc.double() + sh.double()) if fused else x.double()
+    ref = F.conv2d(T.nchw(a64), T.oihw(w.double())).permute(0, 2, 3, 1)
+    assert not torch.isnan(y1).any() and float((y1.double() - ref).abs().max()) <= (2e-6 + 6e-8 * Cin ** 0.5) * float(ref.abs().max()) + 1e-6
+    assert g1 == g0 == ((M + 63) // 64, 64)
+    assert torch.equal(y1, y0) and torch.equal(p1, p0), "the row walker reproduces k_conv_fwd bit for bit (output and BatchNorm partials)"
+    assert torch.equal(y2, y1) and torch.equal(y3, y1) and torch.equal(p3, p1)
