@@ -14,7 +14,7 @@ from collections import defaultdict
 
 
 def klass(name):
-    if "k_conv_fwd" in name or "k_stem_fwd" in name:
+    if "k_conv_fwd" in name or "k_stem_fwd" in name or "k_conv1x1_rows" in name:
         return "conv_fwd"
     if "k_conv_dgrad" in name:
         return "conv_dgrad"
