@@ -292,6 +292,98 @@ static float run9(const float* X, const float* W, float* Y, int M, int N, int K,
     return ms / reps;
 }
 
+
+// V11 (round 4): PERSISTENT workgroups with cross-tile prefetch. grid = min(tiles, 8 per CU); a workgroup walks tiles wg, wg + G, ...
+// (same XCD-aware tile order as V0) and treats their K tiles as ONE stream: behind the last K tile of a tile it fetches the first K
+// tile of the NEXT one, before the MFMAs and the epilogue, so no tile but the first pays a prologue round trip, no workgroup is
+// launched per tile, and a new tile's first instructions are not the youngest wave's (tools/wg_timeline.py: 7-35 us prologues).
+__global__ __launch_bounds__(256, 8) void k_gemm_persist(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int M,
+                                                        int N, int K, int MT, int NT, int ntiles_padded) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int kq = tid & 7, lr = tid >> 3;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(X, M * K * 4), rw = make_rsrc(W, N * K * 4);
+    const int T = K / BK;
+    const int G = gridDim.x;
+    float* sA = smem; float* sB = sA + 64 * LDR;
+    const int h4 = (lane >> 5) * 4, l31 = lane & 31;
+    auto tile_of = [&](int b, int& mt, int& nt) {
+        const int xcd = b & 7, slot = b >> 3;
+        nt = slot % NT; mt = (slot / NT) * 8 + xcd;
+        return mt < MT;
+    };
+    uint32_t a_off[2], b_off[2];
+    auto offsets = [&](int mt, int nt) {
+        for (int i = 0; i < 2; ++i) {
+            const int m = mt * 64 + lr + 32 * i;
+            a_off[i] = m < M ? (uint32_t)((m * K + kq * 4) * 4) : 0x80000000u;
+            b_off[i] = (uint32_t)(((nt * 64 + lr + 32 * i) * K + kq * 4) * 4);
+        }
+    };
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int t) {
+        for (int i = 0; i < 2; ++i) { ra[i] = bld4(rx, a_off[i], (uint32_t)(t * BK * 4)); rb[i] = bld4(rw, b_off[i], (uint32_t)(t * BK * 4)); }
+    };
+    auto sstore = [&]() {
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+            *reinterpret_cast<f32x4*>(sB + (lr + 32 * i) * LDR + kq * 4) = rb[i];
+        }
+    };
+    int b = blockIdx.x, mt, nt;
+    while (b < ntiles_padded && !tile_of(b, mt, nt)) b += G;
+    if (b >= ntiles_padded) return;
+    offsets(mt, nt);
+    gload(0); sstore();
+    __syncthreads();
+    while (true) {
+        int bn = b + G, mtn = 0, ntn = 0;
+        while (bn < ntiles_padded && !tile_of(bn, mtn, ntn)) bn += G;
+        const bool has_next = bn < ntiles_padded;
+        f32x16 acc;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) gload(t + 1);
+            else if (has_next) { offsets(mtn, ntn); gload(0); }     // the next tile's first K tile, behind this tile's last
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sA + (wm * 32 + l31) * LDR + 8 * j + h4);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(sB + (wn * 32 + l31) * LDR + 8 * j + h4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bb[e], acc, 0, 0, 0);
+            }
+            __syncthreads();
+            if (t + 1 < T) { sstore(); __syncthreads(); }
+        }
+        // epilogue of tile (mt, nt) (the generic store pattern of V0), then the prefetched K tile goes to LDS
+        const int col = nt * 64 + wn * 32 + (lane & 31);
+        for (int r = 0; r < 16; ++r) {
+            const int m = mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < M) Y[(size_t)m * N + col] = acc[r];
+        }
+        if (!has_next) break;
+        sstore();
+        __syncthreads();
+        b = bn; mt = mtn; nt = ntn;
+    }
+}
+static float run11(const float* X, const float* W, float* Y, int M, int N, int K, int reps) {
+    const int MT = (M + 63) / 64, NT = N / 64;
+    const int padded = (MT + 7) / 8 * 8 * NT;
+    const int grid = padded < 8 * 256 ? padded : 8 * 256;
+    const size_t smem = (size_t)128 * LDR * sizeof(float);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_gemm_persist, dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT, padded);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_gemm_persist, dim3(grid), dim3(256), smem, 0, X, W, Y, M, N, K, MT, NT, padded);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
 static int g_warm_launches = 30;   // back-to-back launches in front of the stamped one (`steady` mode: enough for ~0.4 s of load)
 template <int V>
 static double clock_ghz(const float* X, const float* W, float* Y, int M, int N, int K) {
@@ -393,9 +485,43 @@ static int steady_mode() {
     return 0;
 }
 
+
+// `conv_ablate persist`: V0 (one workgroup per tile) against V11 (persistent workgroups, cross-tile prefetch) in steady state, with a
+// bitwise comparison of the outputs (same K order per tile).
+static int persist_mode() {
+    struct Shape { int M, N, K; const char* what; };
+    const Shape shapes[] = {{401408, 256, 64, "64->256 1x1 @56"}, {401408, 64, 256, "256->64 1x1 @56"}, {100352, 512, 128, "128->512 1x1 @28"},
+                            {100352, 128, 512, "512->128 1x1 @28"}, {25088, 1024, 256, "256->1024 1x1 @14"}, {25088, 256, 1024, "1024->256 1x1 @14"},
+                            {25088, 256, 2304, "256->256 3x3 @14 as GEMM"}, {6272, 2048, 512, "512->2048 1x1 @7"}, {6272, 512, 2048, "2048->512 1x1 @7"}};
+    for (const Shape& s : shapes) {
+        float *X, *W, *Y;
+        hipMalloc(&X, (size_t)s.M * s.K * 4); hipMalloc(&W, (size_t)s.N * s.K * 4); hipMalloc(&Y, (size_t)s.M * s.N * 4);
+        std::vector<float> h((size_t)s.M * s.K);
+        for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+        hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(W, h.data(), (size_t)s.N * s.K * 4, hipMemcpyHostToDevice);
+        const double gflop = 2.0 * s.M * s.N * s.K / 1e9;
+        std::vector<float> y0((size_t)s.M * s.N), y1((size_t)s.M * s.N);
+        run<0>(X, W, Y, s.M, s.N, s.K, 1); hipMemcpy(y0.data(), Y, y0.size() * 4, hipMemcpyDeviceToHost);
+        hipMemset(Y, 0, y0.size() * 4);
+        run11(X, W, Y, s.M, s.N, s.K, 1); hipMemcpy(y1.data(), Y, y1.size() * 4, hipMemcpyDeviceToHost);
+        size_t bad = 0; for (size_t i = 0; i < y0.size(); ++i) bad += y0[i] != y1[i];
+        const float t_cold = run<0>(X, W, Y, s.M, s.N, s.K, 10);
+        const int n = (int)(300.0f / t_cold) + 30;
+        float a[3], b[3];
+        for (int r = 0; r < 3; ++r) { a[r] = run<0>(X, W, Y, s.M, s.N, s.K, n); b[r] = run11(X, W, Y, s.M, s.N, s.K, n); }
+        std::sort(a, a + 3); std::sort(b, b + 3);
+        printf("%-26s %6.2f tiles/CU T=%3d | one workgroup per tile %.1f TFLOP/s | persistent + cross-tile prefetch %.1f TFLOP/s (%+.1f %%) | %zu outputs differ\n",
+               s.what, (s.M + 63) / 64 * (s.N / 64) / 256.0, s.K / 32, gflop / a[1], gflop / b[1], 100.0 * (a[1] / b[1] - 1.0), bad);
+        hipFree(X); hipFree(W); hipFree(Y);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "long")) return long_mode();
     if (argc > 1 && !strcmp(argv[1], "steady")) return steady_mode();
+    if (argc > 1 && !strcmp(argv[1], "persist")) return persist_mode();
     struct Shape { int M, N, K; const char* what; };
     const Shape shapes[] = {{100352, 128, 512, "512->128 1x1 @28 (B=128)"}, {25088, 256, 2304, "256->256 3x3 @14 as GEMM"},
                             {401408, 256, 64, "64->256 1x1 @56"}, {25088, 1024, 256, "256->1024 1x1 @14"},
