@@ -344,11 +344,12 @@ def test_input_gradient_forms_at_production_batch(cuda, key, B):
         assert e <= 2e-5, f"sum g * xhat{i}: {e:.2e}"
 
 
-@pytest.mark.parametrize("C,B,logit_bias", [(30, 128, False)])
+@pytest.mark.parametrize("C,B,logit_bias", [(30, 128, False), (152, 256, False)])
 def test_whole_network_train_forward_at_production_batch(cuda, C, B, logit_bias):
-    """ResNet50.forward (reference model.py:28-39) in train mode on the benchmark's own workload shape: Protocol 2 (C = 30), B = 128,
-    224 x 224. max |logit - fp64 oracle| <= 1e-4 — BASELINE.json's tolerance on BASELINE.json's configuration — plus the features
-    and the BatchNorm running-statistics update (momentum 0.1, unbiased variance) of all 53 layers."""
+    """ResNet50.forward (reference model.py:28-39) in train mode on the benchmark's own workload shapes: Protocol 2 (C = 30, B = 128)
+    and Protocol 3 (C = 152, B = 256 — BASELINE.json's largest per-GPU configuration), 224 x 224. max |logit - fp64 oracle| <= 1e-4 —
+    BASELINE.json's tolerance on BASELINE.json's configurations — plus the features and the BatchNorm running-statistics update
+    (momentum 0.1, unbiased variance) of all 53 layers."""
     from openset_imagenet import ResNet50
     from oracle import resnet50_oracle as R
     gen = torch.Generator().manual_seed(1234)
