@@ -81,6 +81,46 @@ def test_all_gradients_vs_fp64_oracle_under_the_hip_gates(cuda, tag, B, HW, C, s
     assert np.median(list(errs.values())) <= 1.5e-4
 
 
+def test_all_gradients_at_the_benchmarked_batch(cuda):
+    """The same check on the BENCHMARK's own configuration: Protocol 2 (C = 30, entropic open-set loss), B = 128 at 224 x 224 — the
+    executor's production launch plans, scratch-buffer recycling and side-stream overlap at full size. One fp64 oracle forward + backward
+    under the HIP path's decisions (~1 minute and ~40 GB on the box's CPUs; the free-running second pass of the small cases is skipped)."""
+    import time
+    from openset_imagenet import ResNet50, EntropicOpensetLoss
+    from oracle import resnet50_oracle as R, losses_oracle as L
+    from osi_testlib import hip_gates
+    C, B = 30, 128
+    gen = torch.Generator().manual_seed(77)
+    sd = R.randomize_bn(R.init_state(C, C, False, generator=gen), generator=gen)
+    model = ResNet50(C, C, False)
+    model.load_state_dict(sd)
+    model = model.to(cuda).train()
+    x = torch.rand(B, 3, 224, 224, generator=gen)
+    y = torch.randint(0, C, (B,), generator=gen)
+    y[torch.rand(B, generator=gen) < 0.5] = -1
+    logits, _ = model(x.to(cuda))
+    j = EntropicOpensetLoss(C, 1.0)(logits, y.to(cuda))
+    j.backward()
+    torch.cuda.synchronize()
+    gates = hip_gates(model)
+    t0 = time.time()
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    r_pin = R.forward_backward(sd64, x.double(), y, lambda lg, t, f: L.entropic_openset_loss(lg, t, 1.0), gates=gates)
+    del gates
+    import resource
+    print(f"fp64 oracle forward + backward at B = {B}: {time.time() - t0:.0f} s, peak host memory {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20:.1f} GiB")
+    assert float((logits.detach().cpu().double() - r_pin[0]).abs().max()) <= LOGIT_TOL
+    assert abs(float(j.detach()) - float(r_pin[2])) <= 1e-5 * max(1.0, abs(float(r_pin[2])))
+    named = dict(model.named_parameters())
+    errs = {k: _rel(named[k].grad.detach().cpu(), r_pin[3][k]) for k in R.param_keys(sd)}
+    worst = max(errs, key=errs.get)
+    print(f"B = {B}, 224 x 224, C = {C}: gradient rel-L2 vs fp64 under the HIP gates: median {np.median(list(errs.values())):.2e} max {errs[worst]:.2e} ({worst})")
+    assert len(errs) == 162
+    for k, e in errs.items():
+        assert e <= GRAD_TOL, f"grad {k}: rel-L2 {e:.2e} > {GRAD_TOL:.0e} under pinned gates"
+    assert np.median(list(errs.values())) <= 1.5e-4
+
+
 def test_gates_read_back_are_the_decisions_the_forward_took(cuda):
     """The debug read-out against an independent recomputation: block-output gates == (stored activation > 0), the stem gate ==
     (pooled value > 0) with the arg-max pointing at an element that attains the window maximum of the oracle's bn1 output."""
