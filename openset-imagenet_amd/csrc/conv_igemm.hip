@@ -1124,6 +1124,12 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 4 : (WM * WN == 2 ?
 // registers; the 18 MFMAs of a K step are independent (no accumulator latency exposed). dY traffic / 9, X traffic / (9 / window
 // amplification), LDS reads 12 per 18 MFMAs.
 // ======================================================================================================
+// Diagnostic builds only (make ablate; tools/probes/wgrad3_ablate.sh): -DOSI_ABLATE=<bits> compiles parts of the K loop out — 1 no global
+// loads inside the loop, 2 no register-side staging / LDS stores, 4 no barriers, 8 no tap mask, 16 no LDS operand reads. Wrong results,
+// right timing: how the tap mask (17 - 20 % of the kernel as a test + compare + select per tap) and the staging bubble were priced.
+#ifndef OSI_ABLATE
+#define OSI_ABLATE 0
+#endif
 constexpr int W3_BKP = 32;                 // pixels per K tile
 constexpr int W3_LDA = 64 + 16;            // dY image row stride (floats): 16 consecutive cout x 4 pixels per ds_read_b32 -> two pixel rows
 constexpr int W3_LDB = 32 + 16;            //   land on disjoint bank halves when the stride is 16 mod 32
@@ -1214,17 +1220,22 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
         }
         }
     };
+    uint32_t mbits = 0;
     auto sstore = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(sA + (a_row + 16 * i) * W3_LDA + a_c4 * 4) = ra[i];
 #pragma unroll
-        for (int i = 0; i < NWIN; ++i) {
-            f32x4 v = rb[i];
-            if (XF) {      // fused input activation; rows outside the tensor become relu(shift) garbage, which the tap mask removes
+        for (int i = 0; i < NWIN; ++i) *reinterpret_cast<f32x4*>(sB + (b_row + 32 * i) * W3_LDB + b_c4 * 4) = rb[i];
+        if (tid < W3_BKP) sM[tid] = mbits;
+    };
+    // register-side half of the staging, run BEFORE the barrier that frees the LDS images (the loads were issued a whole run earlier):
+    // the fused input activation in place and the tap-validity bits of the next run; between the two barriers only LDS stores are left
+    auto xform = [&](int t) {
+        if (XF) {      // rows outside the tensor become relu(shift) garbage, which the tap mask removes
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], xsc[e], xsh[e]), 0.f);
-            }
-            *reinterpret_cast<f32x4*>(sB + (b_row + 32 * i) * W3_LDB + b_c4 * 4) = v;
+            for (int i = 0; i < NWIN; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[i][e] = fmaxf(__builtin_fmaf(rb[i][e], xsc[e], xsh[e]), 0.f);
         }
         if (tid < W3_BKP) {                 // tap validity of pixel q: bit (3 r + s) set when (h + r - 1, w + s - 1) is inside the image
             const int q = kbeg + t * W3_BKP + tid;
@@ -1239,74 +1250,102 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
 #pragma unroll
                 for (int r = 0; r < 3; ++r) if ((rowm >> r) & 1) bits |= colm << (3 * r);
             }
-            sM[tid] = bits;
+            mbits = bits;
         }
     };
 
     const int l15 = lane & 15, lk = lane >> 4;
-    // row offset of tap (r, s) inside the window: stride 1: (r W + s); stride 2: the start of the tap's sub-grid run + its shift
-    int tapoff[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int sx = 0; sx < 3; ++sx) {
-            int o = r * W + sx;
-            if (S2) {
-                const int Wo = p.Wo;
-                const int pq = (r != 1 ? 2 : 0) + (sx != 1 ? 1 : 0);
-                const int base = pq == 0 ? 0 : pq == 1 ? 32 : pq == 2 ? 65 : 97 + Wo;
-                o = base + (r == 2 ? Wo : 0) + (sx == 2 ? 1 : 0);
-            }
-            tapoff[3 * r + sx] = o * W3_LDB;
-        }
+    // Row of tap (r, s) inside the window = j * Wx + imm with a compile-time imm: stride 1: r * W + s; stride 2 (the four sub-grid runs
+    // laid end to end, see above): ee at 0, eo at 32, oe at 65, oo at 97 + Wo, plus Wo for r = 2 and 1 for s = 2. Three base pointers
+    // (j = 0, 1, 2) per lane and every LDS read of a run is base + immediate: no address arithmetic inside the K loop.
+    const int Wx = S2 ? p.Wo : W;
+    const float* const bp0 = sB + lk * W3_LDB + 16 * wc + l15;
+    const float* const bj[3] = {bp0, bp0 + Wx * W3_LDB, bp0 + 2 * Wx * W3_LDB};
+    const float* const ap0 = sA + lk * W3_LDA + 32 * wn2 + l15;
     if (T > 0) {
         gload(0);
+        xform(0);
         sstore(0);
         __syncthreads();
         OSI_STAMP(p, blockIdx.x, 1);
         for (int t = 0; t < T; ++t) {
-            if (t + 1 < T) gload(t + 1);
+            if (!(OSI_ABLATE & 1)) if (t + 1 < T) gload(t + 1);
             // K steps of 4 pixels, software-pipelined by hand: the 12 LDS reads of step k+1 are issued before the 18 MFMAs of step k
             // (two register sets, ping-pong). Left to itself the compiler either waits for each read right before its MFMA (rolled
             // loop) or hoists every read of the run and spills the accumulators (unrolled loop).
             struct Ops { float a0, a1, b[9]; uint32_t m; };
             auto lds_ops = [&](int ks, Ops& o) {
-                const int kp = 4 * ks + lk;                    // this lane's pixel of the K step
-                o.a0 = sA[kp * W3_LDA + 32 * wn2 + l15]; o.a1 = sA[kp * W3_LDA + 32 * wn2 + 16 + l15];
-                o.m = sM[kp];
-                const float* bp = sB + kp * W3_LDB + 16 * wc + l15;
-#pragma unroll
-                for (int tp = 0; tp < 9; ++tp) o.b[tp] = bp[tapoff[tp]];
-            };
-            auto mma_ops = [&](const Ops& o) {
+                if (OSI_ABLATE & 16) {     // operands stay in registers: a cheap VALU touch keeps the loop from collapsing
+                    o.a0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, o.a0) ^ (uint32_t)ks); return;
+                }
+                o.a0 = ap0[4 * ks * W3_LDA]; o.a1 = ap0[4 * ks * W3_LDA + 16];     // this lane's pixel of the K step: 4 ks + lk
+                if (!(OSI_ABLATE & 8)) o.m = sM[4 * ks + lk];
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) {
-                    const float b = (o.m >> tp) & 1 ? o.b[tp] : 0.f;
-                    acc[tp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0, b, acc[tp][0], 0, 0, 0);
-                    acc[tp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1, b, acc[tp][1], 0, 0, 0);
+                    const int r = tp / 3, sx = tp % 3;
+                    const int jb = !S2 ? r : (r == 2 ? 1 : 0) + (r != 1 && sx != 1 ? 1 : 0);
+                    const int imm = !S2 ? sx : (r != 1 ? (sx != 1 ? 97 : 65) : (sx != 1 ? 32 : 0)) + (sx == 2 ? 1 : 0);
+                    o.b[tp] = bj[jb][(4 * ks + imm) * W3_LDB];
                 }
             };
-            if constexpr (NWIN < 5) {
+            // The validity of (pixel, tap (r, s)) is rowm(pixel, r) & colm(pixel, s): the row part goes onto the dY operand (two masked
+            // copies of a0 / a1), the column part onto the six X operands of s = 0 and s = 2 — four sign-extended bit fields and ten
+            // v_and per K step instead of a bit test, a compare and a select per tap (27; tools/probes/wgrad3_ablate.sh priced the
+            // tap mask at 17 - 20 % of the kernel).
+            auto mma_ops = [&](const Ops& o) {
+                const uint32_t mr0 = (uint32_t)((int)(o.m << 30) >> 31), mr2 = (uint32_t)((int)(o.m << 24) >> 31);   // bits 1, 7: taps (0,1), (2,1)
+                const uint32_t ms0 = (uint32_t)((int)(o.m << 28) >> 31), ms2 = (uint32_t)((int)(o.m << 26) >> 31);   // bits 3, 5: taps (1,0), (1,2)
+                auto band = [](float v, uint32_t m) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & m); };
+                float a0r[3] = {band(o.a0, mr0), o.a0, band(o.a0, mr2)}, a1r[3] = {band(o.a1, mr0), o.a1, band(o.a1, mr2)};
+                if (OSI_ABLATE & 8) { a0r[0] = a0r[2] = o.a0; a1r[0] = a1r[2] = o.a1; }
+                float bm[9];
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) bm[tp] = (OSI_ABLATE & 8) || tp % 3 == 1 ? o.b[tp] : band(o.b[tp], tp % 3 == 0 ? ms0 : ms2);
+                // all fourteen mask instructions first, then eighteen MFMAs back to back: an MFMA that reads the result of the VALU
+                // instruction in front of it waits for it (the scheduler otherwise pairs each v_and with its consumer)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    acc[tp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0r[tp / 3], bm[tp], acc[tp][0], 0, 0, 0);
+                    acc[tp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1r[tp / 3], bm[tp], acc[tp][1], 0, 0, 0);
+                }
+            };
+            if constexpr (!S2) {
                 Ops o0, o1;
+                if (OSI_ABLATE & 16) {
+                    o0.a0 = ra[0][0]; o0.a1 = ra[1][1]; o0.m = 0x1ff;
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) o0.b[tp] = rb[tp % NWIN][tp & 3];
+                    o1 = o0;
+                }
                 lds_ops(0, o0);
-#pragma unroll 1
-                for (int ks = 0; ks < W3_BKP / 4; ks += 2) {
+#pragma unroll
+                for (int ks = 0; ks < W3_BKP / 4; ks += 2) {      // unrolled: every LDS address is a base register + an immediate
                     lds_ops(ks + 1, o1);
                     mma_ops(o0);
+                    __builtin_amdgcn_sched_barrier(0);           // (keeps the reads of later steps from being hoisted: they would spill)
                     if (ks + 2 < W3_BKP / 4) lds_ops(ks + 2, o0);
                     mma_ops(o1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            } else {     // the widest window (W > 31) stages 20 registers of X rows: no room for a second operand set
-#pragma unroll 1
+            } else {     // stride 2 stages 20 - 24 registers of X rows and their sub-grid bookkeeping: no room for a second operand set
+#pragma unroll NWIN == 6 ? 1 : W3_BKP / 4      // (the six-pass window spills when unrolled)
                 for (int ks = 0; ks < W3_BKP / 4; ++ks) {
                     Ops o;
+                    if (OSI_ABLATE & 16) {
+                        o.a0 = ra[0][0]; o.a1 = ra[1][1]; o.m = 0x1ff;
+#pragma unroll
+                        for (int tp = 0; tp < 9; ++tp) o.b[tp] = rb[tp % NWIN][tp & 3];
+                    }
                     lds_ops(ks, o);
                     mma_ops(o);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __syncthreads();                 // every wave is done reading the run
-            if (t + 1 < T) sstore(t + 1);
-            __syncthreads();
+            if (!(OSI_ABLATE & 2)) if (t + 1 < T) xform(t + 1);
+            if (!(OSI_ABLATE & 4)) __syncthreads();                 // every wave is done reading the run
+            if (!(OSI_ABLATE & 2)) if (t + 1 < T) sstore(t + 1);
+            if (!(OSI_ABLATE & 4)) __syncthreads();
         }
         OSI_STAMP(p, blockIdx.x, 2);
     }
