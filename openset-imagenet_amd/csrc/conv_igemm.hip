@@ -181,17 +181,25 @@ __device__ __forceinline__ void mma_RC(const float* sA, const float* sB, int aro
     }
 }
 // A: C image [32][LDA], B: C image [32][LDB]
+// An operand that spans two 32-wide MFMA blocks (WM / WN = 2) is read INTERLEAVED: lane l takes columns 2 l and 2 l + 1 of the wave's 64
+// (block 0 = the even columns, block 1 = the odd ones) with ONE ds_read_b64 whose K-step offset is an immediate. The plain mapping
+// (block i = columns 32 i .. 32 i + 31) made the compiler pair the two 4-byte reads into a ds_read2_b32, whose 8-bit offsets cannot reach
+// the next K step (two rows = 1056 B): every K step paid two address v_adds feeding two reads feeding a wait. The kernel's epilogue
+// un-permutes (cc_index below).
 template <int WM, int WN, int LDA, int LDB, int K0 = 0, int K1 = BK / 2>
 __device__ __forceinline__ void mma_CC(const float* sA, const float* sB, int acol, int bcol, int lane,
                                        f32x16 (&acc)[WM][WN]) {
+    static_assert(WM <= 2 && WN <= 2 && LDA % 2 == 0 && LDB % 2 == 0, "interleaved pairs");
     const int h = lane >> 5, l31 = lane & 31;
+    const float* pa = sA + h * LDA + acol + (WM == 2 ? 2 * l31 : l31);
+    const float* pb = sB + h * LDB + bcol + (WN == 2 ? 2 * l31 : l31);
 #pragma unroll
     for (int ks = K0; ks < K1; ++ks) {
         float a[WM], b[WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) a[i] = sA[(2 * ks + h) * LDA + acol + i * 32 + l31];
-#pragma unroll
-        for (int n = 0; n < WN; ++n) b[n] = sB[(2 * ks + h) * LDB + bcol + n * 32 + l31];
+        if constexpr (WM == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(pa + 2 * ks * LDA); a[0] = v[0]; a[1] = v[1]; }
+        else a[0] = pa[2 * ks * LDA];
+        if constexpr (WN == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(pb + 2 * ks * LDB); b[0] = v[0]; b[1] = v[1]; }
+        else b[0] = pb[2 * ks * LDB];
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1097,17 +1105,20 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 4 : (WM * WN == 2 ?
         OSI_STAMP(p, sidx, 2);
     }
 
+    // mma_CC's interleaved operand mapping: element e of MFMA block i sits at 2 e + i of the wave's 64 when the wave spans two blocks
     float* out = p.y + (size_t)split * p.slab_stride;
     const int colbase = STEM ? ntile * BN : tap * p.Cin + c0;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int n = 0; n < WN; ++n) {
-            const int col = colbase + wn * 32 * WN + n * 32 + (lane & 31);
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                int row = n0 + wm * 32 * WM + i * 32 + acc_row(rr, lane);
-                if (col < p.Ktot) out[(size_t)row * p.Ktot + col] = acc[i][n][rr];
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = n0 + wm * 32 * WM + (WM == 2 ? 2 * acc_row(rr, lane) + i : acc_row(rr, lane));
+            if constexpr (WN == 2) {      // the lane's two columns are neighbours: one 8-byte store (Ktot and every column base are even)
+                const int col = colbase + wn * 64 + 2 * (lane & 31);
+                if (col < p.Ktot) *reinterpret_cast<f32x2*>(out + (size_t)row * p.Ktot + col) = f32x2{acc[i][0][rr], acc[i][1][rr]};
+            } else {
+                const int col = colbase + wn * 32 + (lane & 31);
+                if (col < p.Ktot) out[(size_t)row * p.Ktot + col] = acc[i][0][rr];
             }
         }
     OSI_STAMP(p, sidx, 3);

@@ -6,6 +6,7 @@
 #include "../../include/osi.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define OSI_LAUNCH_CHECK()                                     \
