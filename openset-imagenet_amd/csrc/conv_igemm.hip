@@ -134,6 +134,15 @@ __device__ __forceinline__ bool tile_of_block_split(const ConvP& p, int bid, int
     return mt < p.MT;
 }
 
+// Diagnostic builds only (make ablate -> tools/probes/bin/libosi_hip_abl<bits>.so; tools/probes/ablate.sh): -DOSI_ABLATE=<bits> compiles
+// parts of the four MFMA kernels' K loops out — 1 no global loads inside the loop, 2 no register-side staging / LDS stores, 4 no barriers,
+// 8 no tap mask (all-taps weight gradient), 16 no LDS operand reads (MFMAs from staging registers), 32 no epilogue (forward, input
+// gradient). Wrong results, right timing: how the tap mask (17 - 20 % of k_conv_wgrad3 as a test + compare + select per tap), the
+// address adds of the per-tap weight gradient's operand reads and the price of operand staging were measured. 0 in the product.
+#ifndef OSI_ABLATE
+#define OSI_ABLATE 0
+#endif
+
 // ---- MFMA over one LDS stage -------------------------------------------------------------------------
 // A: R image (rows = GEMM rows), B: R image (rows = GEMM cols)
 // [J0, J1) of the 4 sub-steps of 8 k each: a kernel may split the block to place other work between MFMAs of the same wave
@@ -376,14 +385,23 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     OSI_STAMP(p, blockIdx.x, 1);
     for (int t = t0; t < T; ++t) {
         const int buf = NST == 2 ? ((t - t0) & 1) : 0;
-        if (t + 1 < T) { gload(t + 1); advance(); }
+        if (!(OSI_ABLATE & 1)) if (t + 1 < T) { gload(t + 1); advance(); }
         const float* sA = smem + buf * STAGE;
+        if (OSI_ABLATE & 16) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i % AR][j & 3], rb[n % BR][j & 3], acc[i][n], 0, 0, 0);
+        } else
         mma_RR<WM, WN>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
-        if (NST == 1) __syncthreads();  // every wave is done reading the only stage
-        if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
-        __syncthreads();
+        if (!(OSI_ABLATE & 4)) if (NST == 1) __syncthreads();  // every wave is done reading the only stage
+        if (!(OSI_ABLATE & 2)) if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
+        if (!(OSI_ABLATE & 4)) __syncthreads();
     }
     OSI_STAMP(p, blockIdx.x, 2);
+    if (OSI_ABLATE & 32) { if (acc[0][0][0] == 123.456f) p.y[tid] = acc[0][0][1]; return; }
 
     bool stored = false;
     if constexpr (WM == 1 && WN == 1) {
@@ -774,15 +792,24 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ?
         OSI_STAMP(p, sidx, 1);
             for (int t = t0; t < T; ++t) {
             const int buf = NST == 2 ? ((t - t0) & 1) : 0;
-                if (t + 1 < T) { gload(); advance(); }
+                if (!(OSI_ABLATE & 1)) if (t + 1 < T) { gload(); advance(); }
             const float* sA = smem + buf * STAGE;
+            if (OSI_ABLATE & 16) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i % AR][j & 3], rbv[n % BRN][j & 3], acc[i][n], 0, 0, 0);
+            } else
             mma_RC<WM, WN, LDC>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
-            if (NST == 1) __syncthreads();
-            if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
-            __syncthreads();
+            if (!(OSI_ABLATE & 4)) if (NST == 1) __syncthreads();
+            if (!(OSI_ABLATE & 2)) if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
+            if (!(OSI_ABLATE & 4)) __syncthreads();
         }
         OSI_STAMP(p, sidx, 2);
     }
+    if (OSI_ABLATE & 32) { if (acc[0][0][0] == 123.456f) p.y[tid] = acc[0][0][1]; return; }
 
     if constexpr (WM == 1 && WN == 1) {
         // Vectorised epilogue of the 64x64 tile (the form the executor uses): the accumulators are transposed through LDS so
@@ -1095,12 +1122,20 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 4 : (WM * WN == 2 ?
             const int buf = NST == 2 ? (t & 1) : 0;
             // every wave passed the barrier that ended tile t-1, i.e. finished reading the window that ends with tile t
             if (use_tbl && t + 1 < T && (t + 1) % TW == 0) build_tbl(t + 1);
-            if (t + 1 < T) gload(t + 1);
+            if (!(OSI_ABLATE & 1)) if (t + 1 < T) gload(t + 1);
             const float* sA = smem + buf * STAGE;
+            if (OSI_ABLATE & 16) {
+#pragma unroll
+                for (int ks = 0; ks < BK / 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[0][i & 3], rbv[0][n & 3], acc[i][n], 0, 0, 0);
+            } else
             mma_CC<WM, WN, LDA, LDB>(sA, sA + BK * LDA, wm * 32 * WM, wn * 32 * WN, lane, acc);
-            if (NST == 1) __syncthreads();
-            if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
-            __syncthreads();
+            if (!(OSI_ABLATE & 4)) if (NST == 1) __syncthreads();
+            if (!(OSI_ABLATE & 2)) if (t + 1 < T) sstore(NST == 2 ? (buf ^ 1) : 0);
+            if (!(OSI_ABLATE & 4)) __syncthreads();
         }
         OSI_STAMP(p, sidx, 2);
     }
@@ -1135,12 +1170,6 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 4 : (WM * WN == 2 ?
 // registers; the 18 MFMAs of a K step are independent (no accumulator latency exposed). dY traffic / 9, X traffic / (9 / window
 // amplification), LDS reads 12 per 18 MFMAs.
 // ======================================================================================================
-// Diagnostic builds only (make ablate; tools/probes/wgrad3_ablate.sh): -DOSI_ABLATE=<bits> compiles parts of the K loop out — 1 no global
-// loads inside the loop, 2 no register-side staging / LDS stores, 4 no barriers, 8 no tap mask, 16 no LDS operand reads. Wrong results,
-// right timing: how the tap mask (17 - 20 % of the kernel as a test + compare + select per tap) and the staging bubble were priced.
-#ifndef OSI_ABLATE
-#define OSI_ABLATE 0
-#endif
 constexpr int W3_BKP = 32;                 // pixels per K tile
 constexpr int W3_LDA = 64 + 16;            // dY image row stride (floats): 16 consecutive cout x 4 pixels per ds_read_b32 -> two pixel rows
 constexpr int W3_LDB = 32 + 16;            //   land on disjoint bank halves when the stride is 16 mod 32
