@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
     f32x4 xsc = {0, 0, 0, 0}, xsh = xsc;
     if (XF) { xsc = ld4(p.in_scale + c0 + b_c4 * 4); xsh = ld4(p.in_shift + c0 + b_c4 * 4); }
     // S2: which sub-grid run this thread's window rows belong to and their offset from the run's first output pixel (fixed per thread)
-    int s2_off[NWIN], s2_pq[NWIN];
+    int s2_off[NWIN], s2_pq[NWIN], s2_c[NWIN];
     if (S2) {
         const int Wo = p.Wo;
 #pragma unroll
@@ -1227,6 +1227,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
             else if (j < 97 + Wo) { s2_pq[i] = 2; s2_off[i] = j - 65 - Wo; }
             else { s2_pq[i] = 3; s2_off[i] = j - (97 + Wo) - Wo - 1; }
             if (j >= WIN) s2_pq[i] = -1;
+            s2_c[i] = (s2_pq[i] >> 1) * p.W + (s2_pq[i] & 1);
         }
     }
 
@@ -1242,11 +1243,11 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
             for (int i = 0; i < NWIN; ++i) {
                 const int sq = q0 + s2_off[i];            // flattened pixel of the (p, q) sub-grid = an output-grid index
                 const bool in = s2_pq[i] >= 0 && sq >= 0 && sq < p.M;
+                // sub-grid pixel sq = (b Ho + hi) Wo + wi sits at input pixel (b H + 2 hi + p) W + 2 wi + q = 4 sq - 2 wi + (p W + q) for
+                // H = 2 Ho, W = 2 Wo: ONE division (by Wo) per window row
                 const uint32_t sqq = in ? (uint32_t)sq : 0u;
-                const uint32_t b = fdiv(sqq, p.dHoWo);
-                const uint32_t rem = sqq - b * p.dHoWo.d;
-                const uint32_t hi = fdiv(rem, p.dWo), wi = rem - hi * p.dWo.d;
-                const uint32_t pix = (b * p.H + 2 * hi + (uint32_t)(s2_pq[i] >> 1)) * p.W + 2 * wi + (uint32_t)(s2_pq[i] & 1);
+                const uint32_t wi = sqq - fdiv(sqq, p.dWo) * p.dWo.d;
+                const uint32_t pix = 4 * sqq - 2 * wi + (uint32_t)s2_c[i];
                 rb[i] = bld4(rx, in ? (pix * p.Cin + c0 + b_c4 * 4) * 4 : OOB, 0);
             }
         } else {
