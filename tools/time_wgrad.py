@@ -1,5 +1,5 @@
 """Dev tool: TFLOP/s of the weight gradient of a few 3x3 layers exactly as the executor calls it (fused input activation), after a
-burst that settles the clock; OSI_HIP_LIB selects the library (tools/probes/wgrad3_ablate.sh runs it over ablated builds).
+burst that settles the clock; OSI_HIP_LIB selects the library (tools/probes/ablate.sh runs it over ablated builds).
 usage: python tools/time_wgrad.py [B]"""
 import ctypes, os, sys, time
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
