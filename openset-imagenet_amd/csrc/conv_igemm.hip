@@ -137,7 +137,7 @@ __device__ __forceinline__ bool tile_of_block_split(const ConvP& p, int bid, int
 // Diagnostic builds only (make ablate -> tools/probes/bin/libosi_hip_abl<bits>.so; tools/probes/ablate.sh): -DOSI_ABLATE=<bits> compiles
 // parts of the four MFMA kernels' K loops out — 1 no global loads inside the loop, 2 no register-side staging / LDS stores, 4 no barriers,
 // 8 no tap mask (all-taps weight gradient), 16 no LDS operand reads (MFMAs from staging registers), 32 no epilogue (forward, input
-// gradient). Wrong results, right timing: how the tap mask (17 - 20 % of k_conv_wgrad3 as a test + compare + select per tap), the
+// gradient), 64 forward: the activation rows of a 3x3 layer loaded and transformed for the first tap only (ceiling of a window kernel). Wrong results, right timing: how the tap mask (17 - 20 % of k_conv_wgrad3 as a test + compare + select per tap), the
 // address adds of the per-tap weight gradient's operand reads and the price of operand staging were measured. 0 in the product.
 #ifndef OSI_ABLATE
 #define OSI_ABLATE 0
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
         } else if (p.unit) {   // 1x1 stride-1: row m of the input, K offset in the scalar operand; no VALU at all
 #pragma unroll
             for (int i = 0; i < AR; ++i) ra[i] = bld4(rx, (uint32_t)a_base[i], (uint32_t)(t * BK * 4));
-        } else {
+        } else if (!(OSI_ABLATE & 64) || (r | s) == 0) {     // (64: the activation rows only for the first tap — ceiling of a window kernel)
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const bool ok = (a_taps[i] >> (r * p.S + s)) & 1;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     auto sstore = [&](int buf) {
         float* sA = smem + buf * STAGE;
         float* sB = sA + BM * LDR;
-        if (XF) xform();
+        if (XF && (!(OSI_ABLATE & 64) || p.unit || ld_tap == 0)) xform();
 #pragma unroll
         for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
 #pragma unroll
