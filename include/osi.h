@@ -48,6 +48,8 @@ const char* osi_strerror(int code);
  *   fwd_wide         0 | 1         0        A/B: 64x128 forward tiles wherever Cout % 128 == 0
  *   fwd_rows         0 .. 2        1        1x1 stride-1 forward convolutions with Cin = 64 on the persistent row walker (weight tile resident in LDS,
  *                                           next row tile prefetched) when the launch has >= 8 row tiles per CU; 2 = every eligible shape (Cin = 64 | 128)
+ *   fwd_w3           0 | 1         1        3x3 stride-1 forward convolutions stage ONE activation window per tap row and 32-channel slice (column-
+ *                                           padded coordinates, the three taps of the row run from it) instead of one 64-row tile per tap
  *   dgrad_wide       0 | 1         0        A/B: 64x128 input-gradient tiles wherever Cin % 128 == 0
  *   bn_grid          1 .. 2^20     1024     grid cap of the BatchNorm stream kernels
  *   bn_grid_bwd      1 .. 2^20     1024     the same for the backward apply kernels

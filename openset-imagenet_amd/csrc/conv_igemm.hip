@@ -229,11 +229,19 @@ __device__ __forceinline__ void mma_CC(const float* sA, const float* sB, int aco
 // cost occupancy, which is what these kernels live on)
 // KS: the launch carries a K-split tail (tile_of_block_split); its own instantiation so that the plain kernels keep their scalar
 // register count (<= 80 SGPRs = eight resident 256-thread workgroups per CU)
-template <int WM, int WN, bool STEM, int NST, int XF = 0, bool KS = false>
+// W3 (3x3, stride 1, pad 1, 64x64 tile): ROW WINDOWS. For a fixed tap row r the taps s = 0, 1, 2 read the same activation rows shifted by
+// one pixel, so ONE window per (r, 32-channel slice) is staged — in column-padded coordinates: slot of pixel m = m + m div W, i.e. one
+// zero slot behind every image row, which is the left / right neighbour a border pixel must see: no mask on the MFMA side; the
+// vertical validity stays the loader's select — and the three K tiles run from it, the A fragment of a lane read at its own base row + s.
+// K-tile order (r, slice, s) instead of (r, s, slice). Activation rows loaded / transformed / stored per slice: 9 x 64 -> 3 x <= 78.
+constexpr int W3_WROWS = 78;   // 64 pixels + a pad slot per image row they cross (<= 64 / W + 1, W >= 7) + the two outer neighbours
+template <int WM, int WN, bool STEM, int NST, int XF = 0, bool KS = false, bool W3 = false>
 __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2)) void k_conv_fwd(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int AR = BM / 32, BR = BN / 32;  // float4 loads per thread per stage
-    constexpr int STAGE = (BM + BN) * LDR;
+    static_assert(!W3 || (WM == 1 && WN == 1 && NST == 1 && !STEM && XF != 2), "row windows: the single-buffered 64x64 tile");
+    constexpr int AROWS = W3 ? W3_WROWS : BM;      // rows of the A image in LDS
+    constexpr int AR = W3 ? 3 : BM / 32, BR = BN / 32;  // float4 loads per thread per stage
+    constexpr int STAGE = (AROWS + BN) * LDR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(!(XF && STEM), "the stem reads the image, not an activation");
     OSI_STAMP(p, blockIdx.x, 0); OSI_STAMP_ID(p, blockIdx.x);
@@ -264,6 +272,23 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     bool a_ok[AR];
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.w, p.w_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(XF == 2 ? p.res : p.x, p.x_bytes);   // XF = 2: the shortcut tensor, same shape as x
+    if constexpr (W3) {
+        // window slot u = lr + 32 i <-> padded index q(m0) - 1 + u; a_base: byte offset of the slot's pixel in tap row r = 1 (OOB: pad slot,
+        // past the tensor, past the window); a_taps: bit r set when the pixel's row h + r - 1 is inside the image
+        const uint32_t Wp = (uint32_t)p.W + 1u, q0 = (uint32_t)m0 + fdiv((uint32_t)m0, p.dWo);
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int u = lr + 32 * i, Q = (int)q0 - 1 + u;
+            bool ok = u < W3_WROWS && Q >= 0;
+            const uint32_t Qq = ok ? (uint32_t)Q : 0u, irow = fdiv(Qq, p.cW[0]), col = Qq - irow * Wp, mm = irow * (uint32_t)p.W + col;
+            ok = ok && col < (uint32_t)p.W && mm < (uint32_t)p.M;
+            const uint32_t mq = ok ? mm : 0u, b = fdiv(mq, p.dHoWo), h = fdiv(mq - b * p.dHoWo.d, p.dWo);
+            a_ok[i] = ok; a_h0[i] = 0; a_w0[i] = 0;
+            // (the three validity bits ride in the low bits of the 16-byte-aligned offset: one register per window slot)
+            a_base[i] = ok ? (int)(((mq * (uint32_t)p.Cin + kq * 4) * 4) | (h > 0 ? 1u : 0u) | 2u | ((int)h < p.H - 1 ? 4u : 0u)) : (int)OOB;
+            a_taps[i] = 0;
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int m = m0 + lr + 32 * i;
@@ -304,8 +329,20 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     const int T = (!KS || ks < 0) ? Tall : min(Tall, t0 + p.ks_T);
     int r = 0, s = 0, c0 = 0;  // current tap / channel offset (non-stem)
     if (KS && !STEM && ks > 0) {
-        const int tap = (t0 * BK) / p.Cin;
-        c0 = t0 * BK - tap * p.Cin; r = tap / p.S; s = tap - r * p.S;
+        if constexpr (W3) {            // tile t = (r, slice, s)
+            const int KC3 = 3 * (p.Cin / BK), rem = t0 % KC3;
+            r = t0 / KC3; c0 = (rem / 3) * BK; s = rem % 3;
+        } else {
+            const int tap = (t0 * BK) / p.Cin;
+            c0 = t0 * BK - tap * p.Cin; r = tap / p.S; s = tap - r * p.S;
+        }
+    }
+    int cs = s;              // W3: tap column of the tile the MFMAs are working on (the loader state runs one tile ahead)
+    bool ld_new = false;     // W3: the loaded tile starts a new window (its activation rows sit in ra)
+    int prow = 0;            // W3: window row of this lane's pixel for s = 0 (= its padded index relative to the tile's first)
+    if constexpr (W3) {
+        const uint32_t m = (uint32_t)min(m0 + wm * 32 + (lane & 31), p.M - 1);
+        prow = (int)(m - (uint32_t)m0 + fdiv(m, p.dWo) - fdiv((uint32_t)m0, p.dWo));
     }
     int ld_c0 = 0, ld_tap = 0; // XF: channel offset / tap index of the tile sitting in ra (set by gload, used by sstore)
     f32x4 ra[AR], rb[BR];
@@ -320,6 +357,20 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
         // The run-time form (1x1 stride-1 or generic) is chosen ONCE per tile, outside the unrolled loop: with a branch per load the
         // compiler waited for every outstanding load before the next one (the other form's destination registers count as pending
         // across the join), so the rows of a tile paid one memory round trip each.
+        if constexpr (W3) {
+            ld_new = s == 0 || t == t0;
+            if (ld_new) {
+                if (XF) ld_tap = r;      // (the validity bit of a window row is its tap ROW's)
+#pragma unroll
+                for (int i = 0; i < AR; ++i) {
+                    const bool ok = ((uint32_t)a_base[i] >> r) & 1;
+                    ra[i] = bld4(rx, ok ? (uint32_t)((a_base[i] & ~15) + ((r - 1) * p.W * p.Cin + c0) * 4) : OOB, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i) rb[i] = bld4(rw, w_voff + (uint32_t)(32 * i) * p.Ktot * 4, (uint32_t)(((r * 3 + s) * p.Cin + c0) * 4));
+            return;
+        }
         if (STEM) {
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
@@ -343,7 +394,9 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
         for (int i = 0; i < BR; ++i) rb[i] = bld4(rw, w_voff + (uint32_t)(32 * i) * p.Ktot * 4, (uint32_t)(t * BK * 4));
     };
     auto advance = [&]() {
-        if (!STEM) {
+        if constexpr (W3) {
+            if (++s == 3) { s = 0; c0 += BK; if (c0 == p.Cin) { c0 = 0; ++r; } }
+        } else if (!STEM) {
             c0 += BK;
             if (c0 == p.Cin) { c0 = 0; if (++s == p.S) { s = 0; ++r; } }
         }
@@ -364,16 +417,25 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
             }
             // 1x1 stride-1: only rows past M are invalid and their results are never stored; otherwise padding taps must read as
             // the zero the reference pads the ACTIVATION with
-            const bool ok = ((a_taps[i] >> ld_tap) & 1) != 0;
+            const bool ok = (((W3 ? (uint32_t)a_base[i] : a_taps[i]) >> ld_tap) & 1) != 0;
             ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto sstore = [&](int buf) {
         float* sA = smem + buf * STAGE;
-        float* sB = sA + BM * LDR;
-        if (XF && (!(OSI_ABLATE & 64) || p.unit || ld_tap == 0)) xform();
+        float* sB = sA + AROWS * LDR;
+        if constexpr (W3) {
+            if (ld_new) {
+                if (XF) xform();
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+                for (int i = 0; i < AR; ++i)
+                    if (lr + 32 * i < W3_WROWS) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+            }
+        } else {
+            if (XF && (!(OSI_ABLATE & 64) || p.unit || ld_tap == 0)) xform();
+#pragma unroll
+            for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+        }
 #pragma unroll
         for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(sB + (lr + 32 * i) * LDR + kq * 4) = rb[i];
     };
@@ -394,6 +456,16 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i % AR][j & 3], rb[n % BR][j & 3], acc[i][n], 0, 0, 0);
+        } else if constexpr (W3) {
+            const float* pa = sA + (prow + cs) * LDR + (lane >> 5) * 4;
+            const float* pb = sA + AROWS * LDR + (wn * 32 + (lane & 31)) * LDR + (lane >> 5) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 8 * j), b = *reinterpret_cast<const f32x4*>(pb + 8 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[0][0], 0, 0, 0);
+            }
+            if (++cs == 3) cs = 0;
         } else
         mma_RR<WM, WN>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
         if (!(OSI_ABLATE & 4)) if (NST == 1) __syncthreads();  // every wave is done reading the only stage
@@ -1736,32 +1808,34 @@ static TailPlan plan_tail_split(long MT, int NT, int T) {
 }
 static size_t tail_slab_floats(const TailPlan& t) { return t.S > 1 ? (size_t)t.tiles * t.S * 4096 : 0; }
 
-template <int XF>
+template <int XF, bool W3 = false>
 static int launch_fwd_split(ConvP p, const TailPlan& tp, float* slab, hipStream_t st) {
     p.MT = osi_cdiv(p.M, 64); p.NT = p.Cout / 64;
     p.MT1 = tp.MT1; p.ks_S = tp.S; p.ks_T = tp.ksT; p.ks_slab = slab;
     p.g1 = osi_cdiv(p.MT1, 8) * 8 * p.NT;
     const int keys = (p.MT - p.MT1) * tp.S;
     const int grid = p.g1 + osi_cdiv(keys, 8) * 8 * p.NT;
-    size_t smem = (size_t)(64 + 64) * LDR * sizeof(float);
+    size_t smem = (size_t)((W3 ? W3_WROWS : 64) + 64) * LDR * sizeof(float);
     if (XF) smem += (size_t)2 * p.Cin * sizeof(float);
-    if (int e = set_smem(k_conv_fwd<1, 1, false, 1, XF, true>, smem)) return e;
-    hipLaunchKernelGGL((k_conv_fwd<1, 1, false, 1, XF, true>), dim3(grid), dim3(256), smem, st, p);
+    if (W3) p.cW[0] = make_fastdiv((uint32_t)p.W + 1);     // row windows: division by the padded row length
+    if (int e = set_smem(k_conv_fwd<1, 1, false, 1, XF, true, W3>, smem)) return e;
+    hipLaunchKernelGGL((k_conv_fwd<1, 1, false, 1, XF, true, W3>), dim3(grid), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_conv_fwd_tail_fixup, dim3(tp.tiles), dim3(256), 0, st, p);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
 
-template <int WM, int WN, bool STEM, int NST = 2, int XF = 0>
+template <int WM, int WN, bool STEM, int NST = 2, int XF = 0, bool W3 = false>
 static int launch_fwd(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     p.MT = osi_cdiv(p.M, BM); p.NT = p.Cout / BN;
-    size_t smem = NST * (size_t)(BM + BN) * LDR * sizeof(float);
+    size_t smem = NST * (size_t)((W3 ? W3_WROWS : BM) + BN) * LDR * sizeof(float);
     if (XF) smem += (size_t)2 * p.Cin * sizeof(float);
-    if (int e = set_smem(k_conv_fwd<WM, WN, STEM, NST, XF>, smem)) return e;
+    if (W3) p.cW[0] = make_fastdiv((uint32_t)p.W + 1);     // row windows: division by the padded row length
+    if (int e = set_smem(k_conv_fwd<WM, WN, STEM, NST, XF, false, W3>, smem)) return e;
     int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
-    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM, NST, XF>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM, NST, XF, false, W3>), dim3(grid), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
@@ -2087,15 +2161,23 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
         if (d->Cin == 64) return in_scale ? launch_fwd_rows<2, 1>(p, st) : launch_fwd_rows<2, 0>(p, st);
         return in_scale ? launch_fwd_rows<4, 1>(p, st) : launch_fwd_rows<4, 0>(p, st);
     }
+    // 3x3 / stride 1 / pad 1 on the row-window form (one activation window per tap ROW and channel slice, see k_conv_fwd W3)
+    const bool w3 = tile == OSI_TILE_AUTO && g_osi_tuning.fwd_w3 && !res && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->W >= 7 &&
+                    d->H == d->Ho && d->W == d->Wo;
     if (tile == OSI_TILE_AUTO && pstats) {
         // ragged last round split along K (plan_tail_split) when the caller's workspace has room for the slab behind the statistics
         const TailPlan tp = fwd_tail_plan(d);
         if (tp.S > 1 && pstats_bytes >= (fwd_stats_floats(d) + tail_slab_floats(tp)) * sizeof(float)) {
             if (int e = with_stats(64)) return e;
             float* slab = pstats + fwd_stats_floats(d);
+            if (w3) return in_scale ? launch_fwd_split<1, true>(p, tp, slab, st) : launch_fwd_split<0, true>(p, tp, slab, st);
             if (in_scale) return res ? launch_fwd_split<2>(p, tp, slab, st) : launch_fwd_split<1>(p, tp, slab, st);
             return launch_fwd_split<0>(p, tp, slab, st);
         }
+    }
+    if (w3) {
+        if (int e = with_stats(64)) return e;
+        return in_scale ? launch_fwd<1, 1, false, 1, 1, true>(p, st) : launch_fwd<1, 1, false, 1, 0, true>(p, st);
     }
     if (tile == OSI_TILE_AUTO) {
         // Measured on MI355X over the 22 ResNet-50 shapes at B=128 (tools/bench_conv.py, profiles/conv_layers_r01.txt): many
