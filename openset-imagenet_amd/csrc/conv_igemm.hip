@@ -734,16 +734,21 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
 // KS: the launch carries a K-split tail (stride 1 only; see tile_of_block_split), its own instantiation like k_conv_fwd's
 // POOL: pool-mode reductions in the epilogue (osi_dgrad_fusion.pool_idx) — one launch per step, its own instantiation so that the
 // workhorse keeps its 8 waves per SIMD
-template <int WM, int WN, int NST, int FUSED, bool KS = false, bool POOL = false>
+// W3 (3x3, stride 1, pad 1, 64x64 tile): row windows as in k_conv_fwd — for a fixed tap row jr the taps js = 0, 1, 2 read the same dY rows
+// shifted by one pixel (dY pixel of (m, jr, js) = m + (1 - jr) W + (1 - js)): one window per (jr, 32-cout slice) in column-padded
+// coordinates, the A fragment of a lane read at its base row + 2 - js. K-tile order (jr, slice, js).
+template <int WM, int WN, int NST, int FUSED, bool KS = false, bool POOL = false, bool W3 = false>
 __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ? 8 : 4)) : 2) void k_conv_dgrad(ConvP p, int Hc0, int Wc0) {
     static_assert(!KS || (WM == 1 && WN == 1 && NST == 1), "the K-split tail is built for the single-buffered 64x64 tile");
+    static_assert(!W3 || (WM == 1 && WN == 1 && NST == 1 && !POOL), "row windows: the single-buffered 64x64 tile");
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int AR = BM / 32;
+    constexpr int AROWS = W3 ? W3_WROWS : BM;
+    constexpr int AR = W3 ? 3 : BM / 32;
     constexpr int LDC = BN + 4;
     constexpr int BV = BN / 4;            // float4 per k-row of the weight tile
     constexpr int BRP = 256 / BV;         // k-rows covered per pass
     constexpr int BRN = BK / BRP;         // passes
-    constexpr int STAGE = BM * LDR + BK * LDC;
+    constexpr int STAGE = AROWS * LDR + BK * LDC;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef OSI_STAMPS
     const size_t sidx = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -784,6 +789,21 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ?
     unsigned a_taps[AR];
     bool a_ok[AR];
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.w, p.w_bytes);
+    if constexpr (W3) {
+        // window slot u = lr + 32 i <-> padded index q(m0) - 1 + u (see k_conv_fwd): a_base = byte offset of the slot's pixel in dY for
+        // jr = 1, with bit jr set in its low bits when row h + 1 - jr is inside the image; OOB: pad slot / past the tensor / past the window
+        const uint32_t Wp = (uint32_t)p.W + 1u, q0 = (uint32_t)m0 + fdiv((uint32_t)m0, dW);
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int u = lr + 32 * i, Q = (int)q0 - 1 + u;
+            bool ok = u < W3_WROWS && Q >= 0;
+            const uint32_t Qq = ok ? (uint32_t)Q : 0u, irow = fdiv(Qq, p.cW[1]), col = Qq - irow * Wp, mm = irow * (uint32_t)p.W + col;
+            ok = ok && col < (uint32_t)p.W && mm < (uint32_t)Mc;
+            const uint32_t mq = ok ? mm : 0u, b = fdiv(mq, dHW), h = fdiv(mq - b * dHW.d, dW);
+            a_ok[i] = ok; a_taps[i] = 0;
+            a_base[i] = ok ? (int)(((mq * (uint32_t)p.Cout + kq * 4) * 4) | ((int)h < p.H - 1 ? 1u : 0u) | 2u | (h > 0 ? 4u : 0u)) : (int)OOB;
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int m = m0 + lr + 32 * i;
@@ -820,14 +840,37 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ?
     const int T = (!KS || ks < 0) ? Tall : min(Tall, t0 + p.ks_T);
     int jr = 0, js = 0, c0 = 0;
     if (KS && ks > 0) {
-        const int tap = t0 / KC;
-        c0 = (t0 - tap * KC) * BK; jr = tap / nS; js = tap - jr * nS;
+        if constexpr (W3) {            // tile t = (jr, slice, js)
+            const int rem = t0 % (3 * KC);
+            jr = t0 / (3 * KC); c0 = (rem / 3) * BK; js = rem % 3;
+        } else {
+            const int tap = t0 / KC;
+            c0 = (t0 - tap * KC) * BK; jr = tap / nS; js = tap - jr * nS;
+        }
+    }
+    int cjs = js;            // W3: tap column of the tile the MFMAs are working on (the loader state runs one tile ahead)
+    bool ld_new = false, first = true;     // W3: the loaded tile starts a new window (its dY rows sit in ra)
+    int prow = 0;            // W3: window row of this lane's pixel for js = 2 (its padded index relative to the tile's first)
+    if constexpr (W3) {
+        const uint32_t m = (uint32_t)min(m0 + wm * 32 + (lane & 31), Mc - 1);
+        prow = (int)(m - (uint32_t)m0 + fdiv(m, dW) - fdiv((uint32_t)m0, dW));
     }
     f32x4 ra[AR], rbv[BRN];
     const int bk_row = tid / BV, bk_col = (tid % BV) * 4;
 
     auto gload = [&]() {
         const int r = rb + st * jr, s = sb + st * js;
+        if constexpr (W3) {
+            ld_new = js == 0 || first;
+            first = false;
+            if (ld_new) {
+#pragma unroll
+                for (int i = 0; i < AR; ++i) {
+                    const bool ok = ((uint32_t)a_base[i] >> jr) & 1;
+                    ra[i] = bld4(rx, ok ? (uint32_t)((a_base[i] & ~15) + ((1 - jr) * p.W * p.Cout + c0) * 4) : OOB, 0);
+                }
+            }
+        } else
         if (p.unit) {   // the form is chosen once per tile, outside the unrolled loop (see k_conv_fwd's gload)
 #pragma unroll
             for (int i = 0; i < AR; ++i) ra[i] = bld4(rx, (uint32_t)a_base[i], (uint32_t)(c0 * 4));
@@ -845,12 +888,23 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ?
             rbv[i] = bld4(rw, (uint32_t)(((bk_row + BRP * i) * p.Ktot + n0 + bk_col) * 4), wsoff);
     };
     auto advance = [&]() {
-        c0 += BK;
-        if (c0 == p.Cout) { c0 = 0; if (++js == nS) { js = 0; ++jr; } }
+        if constexpr (W3) {
+            if (++js == 3) { js = 0; c0 += BK; if (c0 == p.Cout) { c0 = 0; ++jr; } }
+        } else {
+            c0 += BK;
+            if (c0 == p.Cout) { c0 = 0; if (++js == nS) { js = 0; ++jr; } }
+        }
     };
     auto sstore = [&](int buf) {
         float* sA = smem + buf * STAGE;
-        float* sB = sA + BM * LDR;
+        float* sB = sA + AROWS * LDR;
+        if constexpr (W3) {
+            if (ld_new) {
+#pragma unroll
+                for (int i = 0; i < AR; ++i)
+                    if (lr + 32 * i < W3_WROWS) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lr + 32 * i) * LDR + kq * 4) = ra[i];
 #pragma unroll
@@ -873,6 +927,17 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ?
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
                         for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i % AR][j & 3], rbv[n % BRN][j & 3], acc[i][n], 0, 0, 0);
+            } else if constexpr (W3) {
+                const int h4 = (lane >> 5) * 4;
+                const float* pa = sA + (prow + 2 - cjs) * LDR + h4;
+                const float* pb = sA + AROWS * LDR + h4 * LDC + wn * 32 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 8 * j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], pb[(8 * j + e) * LDC], acc[0][0], 0, 0, 0);
+                }
+                if (++cjs == 3) cjs = 0;
             } else
             mma_RC<WM, WN, LDC>(sA, sA + BM * LDR, wm * 32 * WM, wn * 32 * WN, lane, acc);
             if (!(OSI_ABLATE & 4)) if (NST == 1) __syncthreads();
@@ -892,7 +957,12 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ?
         static_assert(BM * LDT <= STAGE, "transposed tile must fit the operand stage");
         float* tile = smem;   // the K loop ended with a barrier: LDS is free
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) tile[(wm * 32 + acc_row(rr, lane)) * LDT + wn * 32 + (lane & 31)] = acc[0][0][rr];
+        for (int rr = 0; rr < 16; ++rr) {
+            // rows past the end of the tensor must be exact zeros for the epilogue's column sums: the per-tap loader gets that from its
+            // range-checked loads, the row-window form reads SOME window row for such a lane and clears the result here
+            const bool live = !W3 || m0 + wm * 32 + acc_row(rr, lane) < Mc;
+            tile[(wm * 32 + acc_row(rr, lane)) * LDT + wn * 32 + (lane & 31)] = live ? acc[0][0][rr] : 0.f;
+        }
         __syncthreads();
         if (KS && ks >= 0) {   // K split of a remainder tile: raw accumulators to the slab, the epilogue runs in k_conv_dgrad_tail_fixup
             float* dst = p.ks_slab + ((size_t)((mt - p.MT1) * p.NT + nt) * p.ks_S + ks) * (BM * BN);
@@ -1860,7 +1930,7 @@ static bool rows_rule(const osi_conv_desc* d, bool unit, const float* res) {
     return m == 2 || (d->Cin == 64 && (long)d->B * d->Ho * d->Wo >= 64L * 8 * hw_cus());
 }
 
-template <int WM, int WN, int NST, int FUSED, bool POOL = false>
+template <int WM, int WN, int NST, int FUSED, bool POOL = false, bool W3 = false>
 static int launch_dgrad_impl(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int s = p.stride;
@@ -1873,16 +1943,17 @@ static int launch_dgrad_impl(ConvP p, hipStream_t st) {
     p.unit = (p.R == 1 && p.S == 1 && s == 1 && p.pad == 0) ? 1 : 0;
     const int Hc = osi_cdiv(p.H, s), Wc = osi_cdiv(p.W, s);  // largest class
     p.MT = osi_cdiv((long)p.B * Hc * Wc, BM); p.NT = p.Cin / BN;
-    size_t smem = 2 * (size_t)(BM * LDR + BK * (BN + 4)) * sizeof(float);
+    size_t smem = 2 * (size_t)((W3 ? W3_WROWS : BM) * LDR + BK * (BN + 4)) * sizeof(float);
     smem = smem / 2 * NST;
-    if (int e = set_smem(k_conv_dgrad<WM, WN, NST, FUSED, false, POOL>, smem)) return e;
+    if (W3) p.cW[1] = make_fastdiv((uint32_t)p.W + 1);     // row windows: division by the padded row length
+    if (int e = set_smem(k_conv_dgrad<WM, WN, NST, FUSED, false, POOL, W3>, smem)) return e;
     int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
-    hipLaunchKernelGGL((k_conv_dgrad<WM, WN, NST, FUSED, false, POOL>), dim3(grid, s * s), dim3(256), smem, st, p, Hc, Wc);
+    hipLaunchKernelGGL((k_conv_dgrad<WM, WN, NST, FUSED, false, POOL, W3>), dim3(grid, s * s), dim3(256), smem, st, p, Hc, Wc);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
 // 64x64 single-buffered input gradient with a K-split tail (stride 1): convolution launch + fix-up pass
-template <int FUSED>
+template <int FUSED, bool W3 = false>
 static int launch_dgrad_split(ConvP p, const TailPlan& tp, float* slab, hipStream_t st) {
     p.cHW[0] = make_fastdiv((uint32_t)(p.H * p.W)); p.cW[0] = make_fastdiv((uint32_t)p.W);
     p.unit = (p.R == 1 && p.S == 1 && p.pad == 0) ? 1 : 0;
@@ -1891,8 +1962,9 @@ static int launch_dgrad_split(ConvP p, const TailPlan& tp, float* slab, hipStrea
     p.g1 = osi_cdiv(p.MT1, 8) * 8 * p.NT;
     const int keys = (p.MT - p.MT1) * tp.S;
     const int grid = p.g1 + osi_cdiv(keys, 8) * 8 * p.NT;
-    const size_t smem = (size_t)(64 * LDR + BK * (64 + 4)) * sizeof(float);
-    hipLaunchKernelGGL((k_conv_dgrad<1, 1, 1, FUSED, true>), dim3(grid, 1), dim3(256), smem, st, p, p.H, p.W);
+    const size_t smem = (size_t)((W3 ? W3_WROWS : 64) * LDR + BK * (64 + 4)) * sizeof(float);
+    if (W3) p.cW[1] = make_fastdiv((uint32_t)p.W + 1);
+    hipLaunchKernelGGL((k_conv_dgrad<1, 1, 1, FUSED, true, false, W3>), dim3(grid, 1), dim3(256), smem, st, p, p.H, p.W);
     OSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_conv_dgrad_tail_fixup<FUSED>, dim3(tp.tiles), dim3(256), 0, st, p);
     OSI_LAUNCH_CHECK();
@@ -2212,6 +2284,10 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
     }
 }
 
+static bool dgrad_w3(const osi_conv_desc* d) {
+    return g_osi_tuning.dgrad_w3 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->W >= 7 && d->H == d->Ho && d->W == d->Wo &&
+           d->Cout % BK == 0 && d->Cin % 64 == 0;
+}
 static int dgrad_rows(int tile) {
     return (tile == OSI_TILE_128x128 || tile == OSI_TILE_128x64 || tile == OSI_TILE_128x128_S1 || tile == OSI_TILE_128x64_S1) ? 128 : 64;
 }
@@ -2294,10 +2370,14 @@ static int conv_dgrad_impl(const osi_conv_desc* d, const float* dy, const float*
             {
                 float* slab = f->partials + dgrad_partial_floats(d);
                 const int fl = dgrad_flavour(p);
+                if (fl == 2 && dgrad_w3(d)) return launch_dgrad_split<2, true>(p, tp, slab, st);
                 return fl == 2 ? launch_dgrad_split<2>(p, tp, slab, st) : fl == 3 ? launch_dgrad_split<3>(p, tp, slab, st) : launch_dgrad_split<1>(p, tp, slab, st);
             }
         }
     }
+    // the executor's in-block 3x3 stride-1 input gradients on the row-window form
+    if (tile == OSI_TILE_64x64_S1 && dgrad_w3(d) && (p.ebits || p.esum || p.escale0) && !p.epool && dgrad_flavour(p) == 2)
+        return launch_dgrad_impl<1, 1, 1, 2, false, true>(p, st);
     switch (tile) {
         case OSI_TILE_128x128: OSI_REQUIRE(d->Cin % 128 == 0); return launch_dgrad<2, 2>(p, st);
         case OSI_TILE_128x64: return launch_dgrad<2, 1>(p, st);

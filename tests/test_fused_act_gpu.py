@@ -121,18 +121,33 @@ def test_dgrad_gate_from_pre_bn_tensor_equals_bitmask(cuda, Cin, Cout, k, stride
     mask = torch.zeros(L.osi_bn_relu_mask_bytes(M, Cin), dtype=torch.uint8, device=cuda)
     N.check(L.osi_bn_apply_relu_mask(N.ptr(y0), None, N.ptr(st[2]), N.ptr(st[3]), N.ptr(out), N.ptr(mask), M, Cin, T.S()))
     pb = L.osi_conv_dgrad_fused_workspace(ctypes.byref(d))
-    res = []
-    for use_bits in (True, False):
-        parts = torch.full((pb // 4,), float("nan"), device=cuda)
-        f = _Fusion(mask.data_ptr() if use_bits else None, y0.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), None, None, None,
-                    parts.data_ptr(), pb, None if use_bits else st[2].data_ptr(), None if use_bits else st[3].data_ptr())
-        gbuf = torch.full((B, H, H, Cin), float("nan"), device=cuda)
-        P = ctypes.c_int()
-        N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(gbuf), None, ctypes.byref(f), 0, ctypes.byref(P), T.S()))
-        res.append((gbuf, parts[:2 * P.value * Cin].clone()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+    def both_routes():
+        res = []
+        for use_bits in (True, False):
+            parts = torch.full((pb // 4,), float("nan"), device=cuda)
+            f = _Fusion(mask.data_ptr() if use_bits else None, y0.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), None, None, None,
+                        parts.data_ptr(), pb, None if use_bits else st[2].data_ptr(), None if use_bits else st[3].data_ptr())
+            gbuf = torch.full((B, H, H, Cin), float("nan"), device=cuda)
+            P = ctypes.c_int()
+            N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(gbuf), None, ctypes.byref(f), 0, ctypes.byref(P), T.S()))
+            res.append((gbuf, parts[:2 * P.value * Cin].clone()))
+        return res
+
     gate = (out > 0).view(B, H, H, Cin)
+    N.check(L.osi_set_tuning(b"dgrad_w3", 0))      # both routes on the same kernel form (same K order): bit for bit
+    try:
+        res = both_routes()
+    finally:
+        N.check(L.osi_set_tuning(b"dgrad_w3", 1))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert bool((res[1][0][~gate] == 0).all()) and float(res[1][0][gate].abs().sum()) > 0
+    # default knobs: the recomputed-gate route of a 3x3 stride-1 layer runs the row-window form (K tiles in another order): the same
+    # gate exactly, the same values up to the summation order
+    rw = both_routes()
+    assert bool((rw[1][0][~gate] == 0).all())
+    assert float((rw[1][0] - res[1][0]).abs().max()) <= 1e-5 * float(res[1][0].abs().max())
+    assert float((rw[1][1] - res[1][1]).abs().max()) <= 1e-4 * float(res[1][1].abs().max())
 
 
 @pytest.mark.parametrize("M,C", [(37, 64), (4 * 49, 2048), (1000, 256)])
