@@ -51,7 +51,6 @@ const char* osi_strerror(int code);
  *   fwd_w3           0 | 1         1        3x3 stride-1 forward convolutions stage ONE activation window per tap row and 32-channel slice (column-
  *                                           padded coordinates, the three taps of the row run from it) instead of one 64-row tile per tap
  *   dgrad_w3         0 | 1         1        the same row windows for the in-block fused 3x3 stride-1 input gradients (dY rows per tap row)
- *   dgrad_w3         0 | 1         1        the same row windows for the in-block fused 3x3 stride-1 input gradients (dY rows per tap row)
  *   dgrad_wide       0 | 1         0        A/B: 64x128 input-gradient tiles wherever Cin % 128 == 0
  *   bn_grid          1 .. 2^20     1024     grid cap of the BatchNorm stream kernels
  *   bn_grid_bwd      1 .. 2^20     1024     the same for the backward apply kernels
