@@ -349,3 +349,52 @@ def test_persistent_row_walker_for_short_k_1x1(cuda, Cin, Cout, H, B, fused):
     assert g1 == g0 == ((M + 63) // 64, 64)
     assert torch.equal(y1, y0) and torch.equal(p1, p0), "the row walker reproduces k_conv_fwd bit for bit (output and BatchNorm partials)"
     assert torch.equal(y2, y1) and torch.equal(y3, y1) and torch.equal(p3, p1)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,B", [(64, 64, 7, 5), (96, 64, 13, 3), (64, 128, 56, 1), (128, 64, 8, 9), (32, 64, 31, 2)])
+def test_row_windows_of_the_3x3_layers(cuda, Cin, Cout, H, B):
+    """fwd_w3 / dgrad_w3 (default on): the 3x3 stride-1 forward and in-block input gradient stage one window per tap ROW in column-padded
+    coordinates instead of one tile per tap. Same results as the per-tap form up to the order of the K tiles — at the smallest width the
+    window is sized for (7), across image boundaries inside a tile, with a ragged last row tile, with and without the fused activation."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    x, sc, sh, w, act64 = _case(cuda, Cin, Cout, 3, 1, H, B)
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, 3, 1, 1)
+    M = B * H * H
+    pb = L.osi_conv_fwd_bnstats_workspace(ctypes.byref(d))
+    ref = F.conv2d(T.nchw(act64), T.oihw(w.double()), None, 1, 1).permute(0, 2, 3, 1)
+    ref_plain = F.conv2d(T.nchw(x.double()), T.oihw(w.double()), None, 1, 1).permute(0, 2, 3, 1)
+    tol = (2e-6 + 6e-8 * (9 * Cin) ** 0.5)
+    out = {}
+    for knob in (1, 0):
+        N.check(L.osi_set_tuning(b"fwd_w3", knob)); N.check(L.osi_set_tuning(b"dgrad_w3", knob))
+        try:
+            y = torch.full((B, H, H, Cout), float("nan"), device=cuda); ps = torch.full((pb // 4,), float("nan"), device=cuda)
+            P, rows = ctypes.c_int(), ctypes.c_int()
+            N.check(L.osi_conv_fwd_act(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(w), N.ptr(y), 0, N.ptr(ps), pb, ctypes.byref(P),
+                                       ctypes.byref(rows), T.S()))
+            yp = torch.full_like(y, float("nan"))
+            N.check(L.osi_conv_fwd_bnstats(ctypes.byref(d), N.ptr(x), N.ptr(w), N.ptr(yp), 0, N.ptr(ps), pb, ctypes.byref(P), ctypes.byref(rows), T.S()))
+            # in-block input gradient of the same layer: dx [B,H,H,Cin] from dy [B,H,H,Cout], gate recomputed from y0, sums over y0
+            g = torch.Generator().manual_seed(Cin + H)
+            dy = torch.randn(B, H, H, Cout, generator=g).to(cuda)
+            y0 = (torch.randn(M, Cin, generator=g) * 2 + 0.3).to(cuda)
+            mean0, inv0 = y0.mean(0), 1 / torch.sqrt(y0.var(0, unbiased=False) + 1e-5)
+            fb = L.osi_conv_dgrad_fused_workspace(ctypes.byref(d)); parts = torch.full((fb // 4,), float("nan"), device=cuda)
+            f = _Fusion(None, y0.data_ptr(), mean0.data_ptr(), inv0.data_ptr(), None, None, None, parts.data_ptr(), fb, sc.data_ptr(), sh.data_ptr())
+            dx = torch.full((B, H, H, Cin), float("nan"), device=cuda)
+            Pd = ctypes.c_int()
+            N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(dx), None, ctypes.byref(f), 0, ctypes.byref(Pd), T.S()))
+            torch.cuda.synchronize()
+            out[knob] = (y, yp, dx, parts[:2 * Pd.value * Cin].clone(), dy, y0)
+        finally:
+            N.check(L.osi_set_tuning(b"fwd_w3", 1)); N.check(L.osi_set_tuning(b"dgrad_w3", 1))
+    y, yp, dx, parts, dy, y0 = out[1]
+    assert float((y.double() - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-6
+    assert float((yp.double() - ref_plain).abs().max()) <= tol * float(ref_plain.abs().max()) + 1e-6
+    gate = ((y0 * sc + sh) > 0).view(B, H, H, Cin)
+    dx64 = F.conv_transpose2d(T.nchw(dy.double()), T.oihw(w.double()), None, 1, 1).permute(0, 2, 3, 1) * gate
+    assert float((dx.double() - dx64).abs().max()) <= (2e-6 + 6e-8 * (9 * Cout) ** 0.5) * float(dx64.abs().max()) + 1e-6
+    for a, b in zip(out[1][:4], out[0][:4]):          # against the per-tap form: the order of the K tiles only
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
