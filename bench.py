@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec of the open-set ImageNet training step (ResNet-50 + entropic open-set loss) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]                       (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W]        any N: for N > 1 this process starts its own N ranks (one child process
+                                                               per GPU; see launch_ranks) and relays rank 0's JSON line
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the same ranks started by torchrun)
 
 One step = the reference's inner-loop body (openset_imagenet/train.py:125-139): zero_grad, forward, loss, backward
 (+ bucketed RCCL gradient all-reduce when N > 1), optimizer step — on a synthetic batch that is already resident in HBM.
@@ -23,10 +24,176 @@ for p in (ROOT, os.path.join(ROOT, "openset-imagenet_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-# RCCL has no API for its channel count (= the workgroups a collective keeps resident on this GPU): rank 0 reads it from the
+
+
+def _cpu_list(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def _cpus_near_gpu(index):
+    """CPUs local to the index-th GPU of the KFD topology (sysfs only — no GPU call): the GPU nodes of
+    /sys/class/kfd/kfd/topology/nodes in node order are HIP's device order when no visibility mask reorders them; the node's PCI
+    address -> /sys/bus/pci/devices/<bdf>/local_cpulist. None when any step does not resolve."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for node in sorted(os.listdir(base), key=int):
+            props = dict(line.split(None, 1) for line in open(os.path.join(base, node, "properties")) if " " in line)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        p = gpus[index]
+        loc = int(p["location_id"])
+        bdf = "%04x:%02x:%02x.%x" % (int(p.get("domain", "0")), (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        return _cpu_list(open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read())
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
+def plan_rank_cpus(n_ranks, policy="auto"):
+    """CPU set of every rank: its share of the CPUs this process may use (os.sched_getaffinity). "near" / "auto": the CPUs local to
+    the rank's GPU (sysfs), dealt out evenly among the ranks that share a locality domain; "even": contiguous equal chunks of the
+    sorted mask; "none": no binding. "auto" falls back to "even" when the topology does not resolve for every rank or a visibility
+    mask (HIP_/ROCR_VISIBLE_DEVICES) may have reordered the devices. Returns (list of CPU lists or None, policy used)."""
+    if policy == "none" or not hasattr(os, "sched_getaffinity"):
+        return None, "none"
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) < n_ranks:
+        return None, "none"
+    if policy in ("auto", "near") and not (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+                                           or os.environ.get("CUDA_VISIBLE_DEVICES")):
+        near = [_cpus_near_gpu(r) for r in range(n_ranks)]
+        if all(near):
+            domains = {}
+            for r, cpus in enumerate(near):
+                domains.setdefault(tuple(sorted(set(cpus) & set(mine))), []).append(r)
+            if all(len(cpus) >= len(ranks) for cpus, ranks in domains.items()):
+                out = [None] * n_ranks
+                for cpus, ranks in domains.items():
+                    per = len(cpus) // len(ranks)
+                    for i, r in enumerate(ranks):
+                        out[r] = list(cpus[i * per:(i + 1) * per])
+                return out, "near"
+    per = len(mine) // n_ranks
+    return [mine[r * per:(r + 1) * per] for r in range(n_ranks)], "even"
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no rank variables in the environment: start the N ranks as CHILD processes of this
+    one (one process per GPU, the reference's intent: config/train.yaml:18,35-39, script/train_all.py:96-99), relay rank 0's single
+    JSON line, and exit non-zero — after terminating the survivors — if any rank fails or the run exceeds --launch-timeout.
+
+    This parent never touches the GPU (torch is not even imported): a process that has initialised the GPU must not be replaced by
+    another, and RCCL wants the devices untouched by anybody but their rank. Visibility masks are passed through unchanged (every
+    rank sees every device and takes LOCAL_RANK), so the `rccl` object of the record carries real PCI ids."""
+    import signal
+    import socket
+    import subprocess
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("OSI_BENCH_LAUNCH_TIMEOUT", "1500")))
+    ap.add_argument("--bind", default=os.environ.get("OSI_BENCH_BIND", "auto"), choices=("auto", "near", "even", "none"))
+    la, _ = ap.parse_known_args(argv)
+    with socket.socket() as s:                   # a free rendezvous port (a constant collides with a neighbour's run)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cpus, policy = plan_rank_cpus(n, la.bind)
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OSI_BENCH_LAUNCHED="1", OSI_BENCH_BIND_POLICY=policy)
+        if cpus:
+            env["OSI_BENCH_CPUS"] = ",".join(map(str, cpus[rank]))
+        # rank 0's stdout is the record; the other ranks print nothing there (anything they do print goes to our stderr)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr.fileno()))
+    print(f"[bench] started {n} ranks, pids {[p.pid for p in procs]}, rendezvous 127.0.0.1:{port}, cpu binding {policy}", file=sys.stderr, flush=True)
+
+    def stop_all(sig=signal.SIGTERM):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)        # exactly the process groups started here
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(signum, _frame):
+        stop_all()
+        raise SystemExit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, on_signal)
+
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + la.launch_timeout
+    failed = None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                failed = f"no result after {la.launch_timeout:.0f} s (--launch-timeout)"
+                break
+            time.sleep(0.1)
+    finally:
+        if failed or any(p.poll() is None for p in procs):
+            stop_all(signal.SIGTERM)
+            t_kill = time.monotonic() + 10
+            while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
+                time.sleep(0.1)
+            stop_all(signal.SIGKILL)
+            for p in procs:
+                p.wait()
+    reader.join(timeout=5)
+    if failed:
+        print(f"bench.py: {failed}; the other ranks were terminated", file=sys.stderr, flush=True)
+        return 1
+    lines = [ln for ln in (out0[0] if out0 else b"").decode(errors="replace").splitlines() if ln.strip()]
+    if len(lines) != 1:
+        print(f"bench.py: rank 0 printed {len(lines)} lines, expected exactly one JSON line", file=sys.stderr, flush=True)
+        return 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def _gpus_arg(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and "-h" not in sys.argv \
+        and "--help" not in sys.argv and _gpus_arg(sys.argv[1:]) > 1:
+    sys.exit(launch_ranks(_gpus_arg(sys.argv[1:]), sys.argv[1:]))      # BEFORE torch is imported: the launcher makes no GPU call
+
+# a rank started by launch_ranks binds itself to its CPU share before torch (and its thread pools) load
+BOUND_CPUS = None
+if os.environ.get("OSI_BENCH_CPUS") and hasattr(os, "sched_setaffinity"):
+    try:
+        os.sched_setaffinity(0, _cpu_list(os.environ["OSI_BENCH_CPUS"]))
+        BOUND_CPUS = sorted(os.sched_getaffinity(0))
+    except OSError:
+        pass
+
+# RCCL has no API for its channel count (= the workgroups a collective keeps resident on this GPU): every rank reads it from the
 # communicator's own INIT log, written to a private file (stdout stays one JSON line). Set before torch loads RCCL.
 RCCL_LOG = None
-if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-dp" in sys.argv) and os.environ.get("RANK", "0") == "0" \
+if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-dp" in sys.argv) \
         and os.environ.get("OSI_BENCH_BACKEND", "nccl") == "nccl" and "NCCL_DEBUG" not in os.environ:
     RCCL_LOG = f"/tmp/osi_rccl_init_{os.getpid()}.log"
     os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_FILE=RCCL_LOG)
@@ -276,9 +443,13 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumentation of the executor")
     ap.add_argument("--force-dp", action="store_true", help="dev: with one rank, still run the data-parallel step (staged backward + "
                     "RCCL bucket all-reduce on a world-1 communicator) to price the N>1 code path on a one-GPU box")
+    ap.add_argument("--sustained-steps", type=int, default=int(os.environ.get("OSI_BENCH_SUSTAINED", "600")),
+                    help="further steps AFTER the timed windows (never part of `value`), reported as `sustained` in 50-step windows; 0 = off")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 self-launch: seconds before the ranks are terminated")
+    ap.add_argument("--bind", default="auto", choices=("auto", "near", "even", "none"), help="N > 1 self-launch: CPU binding of the ranks")
     args = ap.parse_args()
-    if args.windows < 1 or args.steps < 1 or args.warmup < 0 or args.cpus_per_gpu < 1:
-        ap.error("--windows, --steps and --cpus-per-gpu must be >= 1, --warmup >= 0")
+    if args.windows < 1 or args.steps < 1 or args.warmup < 0 or args.cpus_per_gpu < 1 or args.sustained_steps < 0:
+        ap.error("--windows, --steps and --cpus-per-gpu must be >= 1, --warmup and --sustained-steps >= 0")
 
     # stdout carries exactly ONE line (the JSON); anything libraries print on fd 1 (RCCL's version banner, for one) goes to stderr
     sys.stdout.flush()
@@ -288,9 +459,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # fault injection for the launcher's tests (tests/test_bench_launcher.py): "RANK:exit" / "RANK:sleep", before anything touches the GPU
+    for fault in filter(None, os.environ.get("OSI_BENCH_FAULT", "").split(",")):
+        r, _, action = fault.partition(":")
+        if int(r) == rank:
+            if action == "exit":
+                sys.exit(3)
+            time.sleep(3600)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        # `python bench.py --gpus N` starts its own ranks (launch_ranks, top of this file) and torch.distributed.run sets WORLD_SIZE = N;
+        # anything else (a stray RANK without WORLD_SIZE, main() imported and called by hand) is a mis-launch
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: run `python bench.py --gpus N` with no rank variables in the "
+                 "environment (it starts one child process per GPU) or launch the N ranks with torch.distributed.run")
     from openset_imagenet import ResNet50, EntropicOpensetLoss, GarbageLoss, optim, tools, _native as N
     from openset_imagenet.dp import DistributedDataParallel
     N.lib()  # fail loudly if the HIP library is missing
@@ -304,7 +484,13 @@ def main():
     rccl_log = RCCL_LOG
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                sys.exit("bench.py: WORLD_SIZE > 1 without MASTER_PORT — the launcher (bench.py itself, or torch.distributed.run) sets it")
+            import socket
+            with socket.socket() as sk:      # --force-dp at world 1: any free port (a constant collides with a neighbour's run)
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -323,6 +509,23 @@ def main():
             dist.all_reduce = lambda *a, **k: None
         elif os.environ.get("OSI_BENCH_SKIP_COLLECTIVE") == "2": # dev: the four staged backward calls alone (no hand-off either)
             net.sync.world = 1
+    # Under RCCL the collectives keep `channels` workgroups resident beside the backward. The balanced-remainder plan of the forward /
+    # input-gradient launches is told (knob dp_reserved_cus) unless the knob was set by hand; the communicator exists by now (the
+    # wrapper's broadcast created it) and its INIT log names the channel count. MAX over the ranks: one plan everywhere.
+    reserved = None
+    if use_dp and backend == "nccl":
+        from openset_imagenet.dp import reserved_cus_for_channels
+        ch = rccl_channels(rccl_log)
+        if os.environ.get("OSI_DP_RESERVED_CUS"):
+            reserved = {"value": int(os.environ["OSI_DP_RESERVED_CUS"]), "source": "OSI_DP_RESERVED_CUS"}
+        elif ch["coll_channels"] is not None and world > 1:
+            v = torch.tensor([reserved_cus_for_channels(ch["coll_channels"])], device=dev, dtype=torch.int32)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            N.check(N.lib().osi_set_tuning(b"dp_reserved_cus", int(v)))
+            reserved = {"value": int(v), "source": f"ceil({ch['coll_channels']} RCCL channels / 8 workgroup slots per CU), MAX over ranks"}
+        else:
+            reserved = {"value": 0, "source": "default (world 1: nothing is resident beside the backward)" if world == 1
+                        else "default (the RCCL INIT log named no channel count)"}
     opt = optim.Adam(model.parameters(), lr=1e-3)
     images, labels = synthetic_batch(B, C, wl["p_neg"], wl["loss"], dev, 42 + rank)
     if wl["loss"] == "garbage":
@@ -376,6 +579,33 @@ def main():
         windows.append(w)
     elapsed = sorted(windows)[len(windows) // 2]
     loss_value = float(last.detach())
+    # Sustained leg (never part of `value`): the timed region above is a ~2 s burst; this is the same step for --sustained-steps more
+    # steps, one host synchronisation per 50-step window, so that clock / thermal drift shows as a series instead of hiding in a burst.
+    sustained = None
+    if args.sustained_steps >= 50:
+        nwin = args.sustained_steps // 50
+        series = []
+        fence()
+        t_all = time.perf_counter()
+        for _ in range(nwin):
+            t0 = time.perf_counter()
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+            series.append((time.perf_counter() - t0) / 50 * 1e3)
+        fence()
+        total = time.perf_counter() - t_all
+        if world > 1:
+            t = torch.tensor(series + [total], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            series, total = [float(v) for v in t[:-1]], float(t[-1])
+        srt = sorted(series)
+        sustained = {"steps": nwin * 50, "seconds": round(total, 3), "images_per_sec": round(world * B * nwin * 50 / total, 2),
+                     "ms_per_step_mean": round(total / (nwin * 50) * 1e3, 3),
+                     "ms_per_step_p50": round(srt[len(srt) // 2], 3), "ms_per_step_p95": round(srt[min(len(srt) - 1, int(0.95 * len(srt)))], 3),
+                     "first_vs_last_window": round(series[0] / series[-1], 4),
+                     "window_ms_per_step": [round(v, 3) for v in series],
+                     "how": "50-step windows run back to back after the timed region, one synchronize per window (MAX over ranks per window)"}
     if use_dp:     # communication leg: the same step with every bucket's collective bracketed by events (outside the timed windows)
         net.sync.timing(True)
         for _ in range(max(1, min(args.steps, 5))):
@@ -385,7 +615,8 @@ def main():
         net.sync.timing(False)
         # what every rank saw, gathered over the process group itself: a SCALE record must show a straggler or one rank's exposed
         # communication, not only the MAX that `value` is computed from
-        mine = {"rank": rank, "own_ms_per_step_windows": [round(w / args.steps * 1e3, 3) for w in own_windows],
+        mine = {"rank": rank, "cpus": BOUND_CPUS and f"{len(BOUND_CPUS)} CPUs {BOUND_CPUS[0]}..{BOUND_CPUS[-1]}",
+                "own_ms_per_step_windows": [round(w / args.steps * 1e3, 3) for w in own_windows],
                 "exposed_comm_ms": None if comm["exposed_comm_ms"] is None else round(comm["exposed_comm_ms"], 3),
                 "comm_ms_per_step": None if comm["comm_ms_per_step"] is None else round(comm["comm_ms_per_step"], 3)}
         per_rank = [None] * world
@@ -400,6 +631,7 @@ def main():
             N.check(N.lib().osi_get_tuning(name.encode(), ctypes.byref(knob)))
             plan[name] = knob.value
         hw = torch.cuda.get_device_properties(dev).multi_processor_count
+        plan.update(dp_reserved_cus_source=None if reserved is None else reserved["source"])
         plan.update(hw_cus=hw, tail_plan_cus_in_effect=plan["tail_cus"] or max(8, hw - plan["dp_reserved_cus"]),
                     note="CU count the balanced-remainder plan of the forward / input-gradient launches assumes; dp_reserved_cus (OSI_DP_RESERVED_CUS) "
                          "leaves wave slots to RCCL's resident channel workgroups (one 256-thread workgroup per channel = 1/8 of a CU's slots)")
@@ -469,7 +701,11 @@ def main():
                                   "tflops": round(B * g / v["ms_per_step"], 2) if g else None}
                               for (k, v), g in zip(prof.items(), (CONV_GFLOP_FWD, CONV_GFLOP_DGRAD, CONV_GFLOP_WGRAD, 0, 0, 0))},
             }
+        if sustained is not None:
+            sustained["vs_value"] = round(sustained["images_per_sec"] / out["value"], 4)
+            out["sustained"] = sustained
         if rccl is not None:
+            rccl["launcher"] = {"self_launched": os.environ.get("OSI_BENCH_LAUNCHED") == "1", "cpu_binding": os.environ.get("OSI_BENCH_BIND_POLICY")}
             out["rccl"] = rccl
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, wl["p_neg"], gpus_used=world, cpus_per_gpu=args.cpus_per_gpu)

@@ -49,12 +49,20 @@ struct Block {
 };
 
 constexpr size_t ALIGN_F = 64;  // floats (256 B)
-// The executor's events only order streams of ONE device against each other (fork / join of the weight-gradient side stream, reader
-// events of the scratch buffers, the data-parallel hand-off). By default a HIP event performs a SYSTEM-scope fence when it is recorded
-// — a cache writeback + invalidate that makes device memory visible to the host and to other devices — which none of them needs: the
-// kernels on both sides carry their own agent-scope acquire / release. ~115 records per step.
+// The executor's INTERNAL events only order streams of ONE device against each other (fork / join of the weight-gradient side stream,
+// reader events of the scratch buffers). By default a HIP event performs a SYSTEM-scope fence when it is recorded — a cache writeback +
+// invalidate that makes device memory visible to the host and to other devices — which none of them needs: the kernels on both sides
+// carry their own agent-scope acquire / release. ~115 records per step.
 constexpr unsigned EV_FLAGS = hipEventDisableTiming | hipEventDisableSystemFence;
+// The two events of the data-parallel hand-off (osi_resnet50_grads_ready) are different: their consumer is RCCL's all-reduce, whose
+// peers read this device's gradient arena over xGMI. They keep the system-scope release (<= 8 records per step).
+constexpr unsigned EV_FLAGS_HANDOFF = hipEventDisableTiming;
 static size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static int device_cus() {   // CUs of the CURRENT device (the launch plans are balanced for them): 0 when no device answers
+    int v = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return v;
+}
 
 }  // namespace
 
@@ -168,18 +176,23 @@ struct osi_resnet50 {
                                      // kernels never co-run, only HBM-bound work overlaps them. A/B against the default co-running schedule.
     struct PendingW { bool on = false; int ci = 0, gi = 0, in_bn = -1; const float* conv_in = nullptr; float* grads = nullptr; float* ws = nullptr; } pend;
     bool w_inflight = false;
+#ifdef OSI_DIAG                       // `make -C csrc diag` (libosi_hip_diag.so, tools only): the product library has no such switch
     int dbg_skip = 0;                // option "dbg_skip" (TIMING EXPERIMENTS ONLY, results are wrong): bit 0 = the BatchNorm-backward apply passes
                                      // are not launched (their reductions still are), bit 1 = the block-output passes of the forward are
                                      // not launched, bit 2 = with "fwd_recompute" the deferred block-output pass is not launched either — upper bounds for what folding
                                      // those passes into their consumers could buy
+#else
+    static constexpr int dbg_skip = 0;
+#endif
     bool stage_join = true;          // option "stage_join": a staged backward call (stage_hi < stages) ends by joining the side stream into
                                      // the caller's stream. 0 (data parallel): only the LAST stage joins; the caller hands each finished
                                      // stage to its communication stream with osi_resnet50_grads_ready, and the compute stream runs on
     OsiTuning plan_knobs;            // the process-wide knobs the workspace was sized for (osi_resnet50_create); a launch under other
-    int plan_hw_cus = 0;             // values is refused (OSI_ERR_STATE) instead of running a plan the workspace does not fit
+    int plan_hw_cus = 0;             // values (or on a device with another CU count) is refused (OSI_ERR_STATE) instead of running a
+                                     // plan the workspace does not fit
     bool plan_unchanged() const {
         const OsiTuning &a = plan_knobs, &b = g_osi_tuning;
-        return a.wgrad_tile == b.wgrad_tile && a.wgrad_blocks == b.wgrad_blocks && a.wgrad3 == b.wgrad3 && a.wgrad3_blocks == b.wgrad3_blocks &&
+        return plan_hw_cus == device_cus() && a.wgrad_tile == b.wgrad_tile && a.wgrad_blocks == b.wgrad_blocks && a.wgrad3 == b.wgrad3 && a.wgrad3_blocks == b.wgrad3_blocks &&
                a.tail_split == b.tail_split && a.tail_cus == b.tail_cus && a.tail_smax == b.tail_smax && a.tail_mint == b.tail_mint &&
                a.tail_gain == b.tail_gain && a.tail_qmax == b.tail_qmax && a.stem_direct == b.stem_direct && a.wgrad_group == b.wgrad_group &&
                a.dp_reserved_cus == b.dp_reserved_cus;
@@ -316,6 +329,7 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
     n->stem_ws_bytes = osi_stem_wgrad_fused_workspace(&n->convs[0].d);
     n->stem_ws = n->stem_ws_bytes ? n->ws_alloc(n->stem_ws_bytes / 4 + 4) : n->wg_ws;
     n->plan_knobs = g_osi_tuning;
+    n->plan_hw_cus = device_cus();
     n->dg_ws_bytes = dgws; n->dg_ws = n->ws_alloc(dgws / 4 + 4);
     n->scratch_floats = maxact;
     for (int i = 0; i < osi_resnet50::NSCR; ++i) n->scratch[i] = n->ws_alloc(maxact);
@@ -905,8 +919,8 @@ int osi_resnet50_grads_ready(osi_resnet50_t n, osi_stream_t main_stream, osi_str
     OSI_REQUIRE(n);
     hipStream_t mn = (hipStream_t)main_stream, wt = (hipStream_t)waiter_stream;
     if (!n->ev_rmain) {
-        if (hipEventCreateWithFlags(&n->ev_rmain, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
-        if (hipEventCreateWithFlags(&n->ev_rside, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&n->ev_rmain, EV_FLAGS_HANDOFF) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&n->ev_rside, EV_FLAGS_HANDOFF) != hipSuccess) return OSI_ERR_LAUNCH;
     }
     if (hipEventRecord(n->ev_rmain, mn) != hipSuccess) return OSI_ERR_LAUNCH;
     if (hipStreamWaitEvent(wt, n->ev_rmain, 0) != hipSuccess) return OSI_ERR_LAUNCH;
@@ -1021,7 +1035,9 @@ int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
     else if (!strcmp(name, "ds_sparse")) n->ds_sparse = value != 0;
     else if (!strcmp(name, "stem_wgrad_main")) n->stem_wgrad_main = value != 0;
     else if (!strcmp(name, "stage_join")) n->stage_join = value != 0;
+#ifdef OSI_DIAG
     else if (!strcmp(name, "dbg_skip")) n->dbg_skip = value;
+#endif
     else if (!strcmp(name, "side_priority_normal")) {
         if (n->side) return OSI_ERR_STATE;   // the side stream already exists with the other priority
         n->side_prio_normal = value != 0;

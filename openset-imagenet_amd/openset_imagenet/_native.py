@@ -119,6 +119,7 @@ _SIGS = {
 }
 
 _lib = None
+DIAGNOSTIC_LIB = None     # path of a diagnostic build selected with OSI_HIP_LIB + OSI_DEV=1 (never in production)
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -129,8 +130,17 @@ def lib():
     """The loaded shared library; raises NativeLibraryMissing when it has not been built."""
     global _lib, LIB_PATH
     if _lib is None:
-        # dev only: a diagnostic build of the same C ABI (csrc `make stamps`, tools/wg_timeline.py); the product never sets this
-        LIB_PATH = os.environ.get("OSI_HIP_LIB") or LIB_PATH
+        # dev only: a diagnostic build of the same C ABI (csrc `make stamps / diag / ablate`: some of them compute WRONG results by
+        # design). Honoured only together with OSI_DEV=1, announced loudly, and refused by train.worker() (DIAGNOSTIC_LIB).
+        global DIAGNOSTIC_LIB
+        if os.environ.get("OSI_HIP_LIB"):
+            if os.environ.get("OSI_DEV") != "1":
+                raise NativeLibraryMissing("OSI_HIP_LIB selects a diagnostic build of the native library and is only honoured with OSI_DEV=1")
+            LIB_PATH = os.environ["OSI_HIP_LIB"]
+            DIAGNOSTIC_LIB = LIB_PATH
+            import warnings
+            warnings.warn(f"openset_imagenet: DIAGNOSTIC native library {LIB_PATH} (OSI_HIP_LIB + OSI_DEV=1): results may be wrong by design",
+                          RuntimeWarning, stacklevel=2)
         if not os.path.isfile(LIB_PATH):
             raise NativeLibraryMissing(
                 f"{LIB_PATH} not found: build the gfx950 HIP library first (python __graft_entry__.py, or make -C {CSRC_DIR}). "

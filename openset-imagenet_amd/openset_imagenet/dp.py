@@ -23,6 +23,15 @@ import torch.distributed as dist
 from torch import nn
 
 
+def reserved_cus_for_channels(channels, slots_per_cu=8, cap=32):
+    """CUs' worth of wave slots the launch plans should leave to RCCL: a collective keeps one 256-thread workgroup per channel resident,
+    and a CU holds eight such workgroups of the convolution kernels (8 waves per SIMD) — so `channels` workgroups displace
+    ceil(channels / 8) CUs of them while a ring is on the wire. Fed to osi_set_tuning("dp_reserved_cus") before the executor is created."""
+    if not channels or channels <= 0:
+        return 0
+    return min(cap, -(-int(channels) // slots_per_cu))
+
+
 class GradSync:
     """Bucketed asynchronous gradient averaging over a flat arena.
 

@@ -51,7 +51,8 @@ def debug_options_from_env():
     out = {}
     if env.get("OSI_NO_OVERLAP"):
         out["overlap"] = 0
-    if env.get("OSI_DBG_SKIP"):          # timing experiments only (wrong results): see the executor's "dbg_skip"
+    if env.get("OSI_DBG_SKIP") and env.get("OSI_DEV") == "1" and N.DIAGNOSTIC_LIB:
+        # timing experiments only (wrong results): the switch exists in the diagnostic build alone (`make -C csrc diag`, -DOSI_DIAG)
         out["dbg_skip"] = int(env["OSI_DBG_SKIP"])
     if env.get("OSI_FWD_RECOMPUTE") == "1":
         out["fwd_recompute"] = 1

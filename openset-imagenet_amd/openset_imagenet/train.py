@@ -216,6 +216,10 @@ def worker(cfg):
     `cfg.data.synthetic` (new key, default absent) = number of synthetic training samples to use instead of the CSV files."""
     import logging
     import torch.distributed as dist
+    from . import _native
+    _native.lib()
+    if _native.DIAGNOSTIC_LIB:     # OSI_HIP_LIB + OSI_DEV=1: ablated / instrumented builds, some wrong by design — never a training run
+        raise RuntimeError(f"worker(): refusing to train on the diagnostic native library {_native.DIAGNOSTIC_LIB}; unset OSI_HIP_LIB")
     set_seeds(cfg.seed)
     rank, world, local_rank = dist_env()
     distributed = world > 1

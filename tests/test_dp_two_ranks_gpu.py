@@ -38,15 +38,25 @@ def test_two_ranks_share_one_gpu(cuda):
         assert f"rank {rank}: ok" in out
 
 
-def _run_bench(extra_args, env_extra, nproc):
+RANK_VARS = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+
+
+def _run_bench(extra_args, env_extra, nproc, self_launch=False):
+    """self_launch: ONE plain `python bench.py --gpus N` with no rank variables in the environment (bench.py starts its own ranks);
+    otherwise one process per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as torch.distributed.run does."""
     import json
     root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     port = _free_port()
     procs = []
-    for rank in range(nproc):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
-        if nproc > 1:
-            env.update(RANK=str(rank), WORLD_SIZE=str(nproc), LOCAL_RANK=str(rank))
+    base = {k: v for k, v in os.environ.items() if k not in RANK_VARS}
+    if "--sustained-steps" not in extra_args:
+        extra_args = [*extra_args, "--sustained-steps", "0"]
+    for rank in range(1 if self_launch else nproc):
+        env = dict(base, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+        if not self_launch:
+            env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            if nproc > 1:
+                env.update(RANK=str(rank), WORLD_SIZE=str(nproc), LOCAL_RANK=str(rank))
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(nproc), *extra_args], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -91,6 +101,55 @@ def test_bench_two_rank_rehearsal_reports_the_proof_of_ranks(cuda):
     lp = r["launch_plan"]
     assert lp["hw_cus"] == 256 and lp["tail_cus"] == 0 and lp["dp_reserved_cus"] == 0 and lp["tail_plan_cus_in_effect"] == 256 and lp["tail_split"] == 1
     assert r["channels"] is None     # gloo rehearsal: no RCCL communicator
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launch_two_ranks(cuda):
+    """The plain command: `python bench.py --gpus 2` with NO rank variables in the environment starts its own two ranks as child
+    processes (free rendezvous port, per-rank CPU share), relays rank 0's one JSON line and returns 0. Same gloo rehearsal on the one
+    GPU of the test box; the record says it was self-launched and how the ranks were bound."""
+    out = _run_bench(["--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-profile"], {"OSI_BENCH_BACKEND": "gloo"}, 2,
+                     self_launch=True)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    r = out["rccl"]
+    assert r["world"] == 2 and [d["rank"] for d in r["devices"]] == [0, 1]
+    assert r["launcher"]["self_launched"] is True and r["launcher"]["cpu_binding"] in ("near", "even", "none")
+    if r["launcher"]["cpu_binding"] != "none":
+        assert all(q["cpus"] for q in r["per_rank"]) and r["per_rank"][0]["cpus"] != r["per_rank"][1]["cpus"]
+    assert len({d["pid"] for d in r["devices"]} if "pid" in r["devices"][0] else {0, 1}) == 2
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launch_failing_rank(cuda):
+    """A rank that dies takes the launch down: parent rc != 0, no JSON line, and the surviving rank — which by then holds the GPU and
+    waits in the rendezvous — is terminated, not orphaned."""
+    import re
+    import time
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in RANK_VARS}
+    env.update(OSI_BENCH_BACKEND="gloo", OSI_BENCH_FAULT="1:exit")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--batch", "8", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not r.stdout.strip() and "rank 1 exited with code 3" in r.stderr
+    pids = [int(p) for p in re.search(r"pids \[([\d, ]+)\]", r.stderr).group(1).split(",")]
+    time.sleep(1.0)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            state = open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0]
+            assert state == "Z", f"rank process {pid} survived the failed launch"
+        except (ProcessLookupError, OSError):
+            pass
+
+
+@pytest.mark.timeout(900)
+def test_bench_sustained_leg(cuda):
+    """After the timed windows (never part of `value`) the record carries a sustained leg in 50-step windows."""
+    out = _run_bench(["--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-profile", "--sustained-steps", "100"], {}, 1)
+    s = out["sustained"]
+    assert s["steps"] == 100 and len(s["window_ms_per_step"]) == 2 and s["ms_per_step_p50"] <= s["ms_per_step_p95"]
+    assert s["images_per_sec"] == pytest.approx(8 * 100 / s["seconds"], rel=1e-3) and s["vs_value"] > 0
+    assert out["value"] == pytest.approx(8 / (out["ms_per_step"] * 1e-3), rel=1e-2), "`value` comes from the timed windows alone"
 
 
 @pytest.mark.timeout(900)

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../.."
 what=${1:-all}
 run() {   # run <tool> <env assignment or ""> <variants...>
   tool=$1; e=$2; shift 2
-  for round in 1 2; do for v in "$@"; do env $e OSI_HIP_LIB=$PWD/tools/probes/bin/libosi_hip_abl$v.so python tools/$tool 2>/dev/null || exit 1; done; done
+  for round in 1 2; do for v in "$@"; do env $e OSI_DEV=1 OSI_HIP_LIB=$PWD/tools/probes/bin/libosi_hip_abl$v.so python tools/$tool 2>/dev/null || exit 1; done; done
 }
 if [ $what = fwd ] || [ $what = all ]; then
   echo "forward as the executor calls it (a = fused input activation), TFLOP/s at B = 128: 3x3 64@56a | 64->256@56a (row walker: not ablated) | 256->64@56 | 3x3 128@28a | 512->128@28 | 3x3 256@14a | 256->1024@14a | 1024->256@14 | 3x3 512@7a | 512->2048@7a"

@@ -23,6 +23,10 @@ from collections import defaultdict
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "openset-imagenet_amd"), os.path.join(ROOT, "tests")]
 os.environ.setdefault("OSI_HIP_LIB", os.path.join(ROOT, "openset-imagenet_amd", "csrc", "libosi_hip_stamps.so"))
+os.environ["OSI_DEV"] = "1"          # the package only honours OSI_HIP_LIB in dev mode
+if not os.path.isfile(os.environ["OSI_HIP_LIB"]):      # built on demand: __graft_entry__.build() only builds the product
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "openset-imagenet_amd", "csrc"), "stamps"], check=True)
 import torch  # noqa: E402
 from openset_imagenet import _native as N  # noqa: E402
 
