@@ -52,6 +52,8 @@ const char* osi_strerror(int code);
  *                                           padded coordinates, the three taps of the row run from it) instead of one 64-row tile per tap
  *   dgrad_w3         0 | 1         1        the same row windows for the in-block fused 3x3 stride-1 input gradients (dY rows per tap row)
  *   dgrad_wide       0 | 1         0        A/B: 64x128 input-gradient tiles wherever Cin % 128 == 0
+ *   fwd_wino *       0 | 1         1        the executor runs its 3x3 stride-1 forward convolutions in the Winograd F(2x2,3x3) form (osi_conv_fwd_wino)
+ *   dgrad_wino *     0 | 1         1        the same for the in-block fused 3x3 stride-1 input gradients (osi_conv_dgrad_fused_wino)
  *   bn_grid          1 .. 2^20     1024     grid cap of the BatchNorm stream kernels
  *   bn_grid_bwd      1 .. 2^20     1024     the same for the backward apply kernels
  *   bn_single_p      1 .. 2^20     128      BatchNorm partials merged by ONE 256-thread launch up to this many row tiles
@@ -100,6 +102,20 @@ int osi_conv_fwd_act(const osi_conv_desc* d, const float* x, const float* in_sca
 int osi_conv_fwd_act2(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* res,
                       const float* w, float* y, int tile, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block,
                       osi_stream_t stream);
+/* Winograd F(2x2, 3x3) forms of the two calls above for 3x3 / stride 1 / pad 1 convolutions (conv2 of the bottlenecks without a stride;
+ * csrc/conv_wino.hip): 2.25x fewer multiplies, every product and sum still fp32 (exact-f32 MFMA), error against fp64 below the direct
+ * kernels' on the network's shapes. `ws` = osi_conv_wino_workspace(d) bytes for the transformed weights (rebuilt by every call: the
+ * weights change every step). osi_conv_wino_eligible: 1 when the shape is taken (Cin % 16 == 0 and Cout % 64 == 0 forward, swapped for the
+ * input gradient; forward: every 16-tile statistics group must hold the same number of pixels — H, W even and B * H/2 * W/2 % 16 == 0, or
+ * whole images per group as at 7 x 7).
+ * osi_conv_fwd_wino = osi_conv_fwd_act (in_scale / in_shift given) or osi_conv_fwd_bnstats (NULL): *P = ceil(tiles / 16) partials of
+ * *rows_per_block pixels for osi_bn_finalize_stats; pstats may be NULL.
+ * osi_conv_dgrad_fused_wino = osi_conv_dgrad_fused restricted to the executor's "in-block" fusion: f->scale0 / shift0 / y0 required (gate
+ * recomputed), no addend / relu_mask / y1 / pool mode; f->partials optional ([3][*P][Cin], planes 0 and 1 written). */
+int osi_conv_wino_eligible(const osi_conv_desc* d, int input_gradient);
+size_t osi_conv_wino_workspace(const osi_conv_desc* d);
+int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
+                      void* ws, size_t ws_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
 /* dx (+)= conv2d_input_grad(dy, w). accumulate = 1 adds into dx (skip-connection sum); accumulate = 2 ("sparse", ABI 4) writes
  * only the input pixels some filter tap reaches and leaves every other element of dx UNTOUCHED (a stride-2 1x1 convolution reaches
  * the pixels with even h and even w: a quarter of the tensor) — for a consumer that knows the pattern, see
@@ -138,6 +154,8 @@ typedef struct {
 size_t osi_conv_dgrad_fused_workspace(const osi_conv_desc* d);
 int osi_conv_dgrad_fused(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const float* addend,
                          const osi_dgrad_fusion* f, int tile, int* P, osi_stream_t stream);
+int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const osi_dgrad_fusion* f, void* ws,
+                              size_t ws_bytes, int* P, osi_stream_t stream);
 /* dw = conv2d_weight_grad(dy, x), deterministic split-K through `ws` (size from osi_conv_wgrad_workspace). The stem writes
  * the packed [Cout][224] form; osi_stem_grad_unpack converts to [Cout][7][7][3]. */
 size_t osi_conv_wgrad_workspace(const osi_conv_desc* d);

@@ -1,0 +1,506 @@
+// Winograd F(2x2, 3x3) on the exact-fp32 matrix cores of gfx950: the thirteen 3x3 / stride 1 / pad 1 convolutions of ResNet-50
+// (conv2 of every bottleneck without a stride: torchvision's resnet50 under /root/reference/openset_imagenet/model.py:17,37) and their
+// input gradients (autograd of train.py:138) with 2.25x fewer multiplies than the implicit GEMM in conv_igemm.hip.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g            (Lavin & Gray 2015)
+//   -> 16 independent GEMMs   M_p[n][tile] = sum_k U_p[n][k] * V_p[k][tile],   p = (xi, nu) in 4 x 4,  k = input channel, n = output channel
+//
+// Arithmetic: every product and sum is fp32 (v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain; the transforms are fp32 adds and the two
+// 0.5 factors of G). Against an fp64 convolution the error is BELOW the direct kernel's on the network's shapes (16 / 64 / ... products
+// per accumulator chain instead of 9 times as many; tools/probes/winograd_f2x2.hip prints both) — the per-kernel parity bound of
+// tests/test_production_shapes_gpu.py is unchanged.
+//
+// Kernel (k_wino): one PERSISTENT workgroup per CU = 4 waves (2 x 2); a unit = 64 tiles x 64 output channels; every wave owns 32 tiles x
+// 32 channels for ALL 16 positions = 16 accumulator sets of 16 registers = 256 AGPRs (one wave per SIMD), so the output transform is
+// register arithmetic. K loop over 16-channel slices:
+//   V (B operand): every thread owns one (tile, 4-channel quad): 16 buffer loads of 16 B (its 4x4 patch; out of the image = the range
+//     check's zeros), the optional fused input activation relu(fma(x, scale, shift)) with the padding selected to zero AFTER it (exactly
+//     osi_conv_fwd_act's operand), B^T d B in registers, 16 ds_write_b128 into V[buf][p][tile][16 ch] — 16-byte chunks XOR-swizzled by
+//     the tile index: conflict-free b128 writes and reads without padding, 2 x 64 KiB double buffered, one barrier per slice;
+//   U (A operand): transformed once per launch by k_wino_weights INTO THE PER-LANE FRAGMENT ORDER and read straight from L2 into
+//     registers (1 KiB contiguous per wave-load), software pipelined PF positions ahead on the in-order vmcnt queue — no LDS.
+// The pipeline runs across units: the last slice of a unit stages the first slice of the workgroup's next unit, so only the first unit
+// pays an exposed prologue. Program order is pinned per position with sched_barrier: the compiler otherwise sinks the loads next to
+// their uses. fp32 MFMA runs at the vector rate — VALU work beside it is NOT hidden, so the patch transform (one clump per position,
+// positions 8..15) is priced in full: ~25 % of the forward form, ~10 % of the input-gradient form (no activation).
+//
+// Epilogues (per lane: one tile = 2 x 2 pixels, 16 channels in 4 quads):
+//   EPI 0 forward: y + optional BatchNorm (mean, M2) partials per 16 tiles (= one DPP row of lanes = 64 pixels, the row-tile size of the
+//     direct kernels: P and rows_per_block feed osi_bn_finalize_stats unchanged), reduced with 4 DPP adds per value — no LDS, no barrier;
+//   EPI 1 input gradient, "in-block" fusion of osi_conv_dgrad_fused: dx = gate . acc with the gate recomputed from the producer's pre-BN
+//     tensor (fma(y0, scale0, shift0) > 0), and the per-64-pixel sums of g and g * xhat0 for the BatchNorm backward of that producer.
+#include "conv_common.h"
+#include <utility>
+
+using namespace osi_conv;
+
+namespace {
+
+constexpr int KC = 16;      // channels per K slice
+constexpr int PF = 6;       // positions the U fragments are loaded ahead
+
+struct WinoP {
+    const float* x;      // operand tensor [B][H][W][Kc] (forward: the conv input, pre-activation when `sc`; input gradient: dY)
+    const float* u;      // transformed weights in fragment order (k_wino_weights)
+    float* y;            // result [B][H][W][Nc]
+    const float* sc;     // fused input activation (forward), or NULL
+    const float* sh;
+    int H, W, Kc, Nc, TH, TW, T, KS, CB, MT, NT;
+    int x_bytes, y_bytes, u_bytes;
+    // forward statistics: [P][Nc] means then [P][Nc] M2, P = ceil(T / 16); cnt = valid pixels of a 16-tile group
+    float* pmean;
+    float* pm2;
+    int P;
+    float cnt, rcnt;
+    // input gradient, in-block epilogue
+    const float* ey0;    // producer's pre-BN tensor, same shape as y
+    const float *escale0, *eshift0, *emean0, *einv0;
+    float* esum;         // [3][P][Nc]: sum g, sum g * xhat0 (third plane unused)
+};
+
+template <class F, int... I>
+__device__ __forceinline__ void for_each_const(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+__device__ __forceinline__ bool unit_of_block(int bid, int MT, int NT, int& mt, int& nt) {
+    const int xcd = bid & 7, slot = bid >> 3;      // all NT column units of a tile block on one XCD's L2
+    nt = slot % NT;
+    mt = (slot / NT) * 8 + xcd;
+    return mt < MT;
+}
+
+// sum over the 16 lanes of a DPP row (= 16 tiles = one statistics group), result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+// U_p = (G g G^T)_p in the order the MFMA A fragments are consumed:
+//   index = ((((p * KS + ks) * CB + cb) * 2 + j) * 64 + lane) * 4 + e   <->   k = 16 ks + 8 j + 4 (lane / 32) + e,  n = 32 cb + lane % 32
+// (lane half h of MFMA (j, e) of a slice consumes channel 8 j + 4 h + e: the order in which V's channels sit in LDS).
+// w: KRSC [Cout][3][3][Cin].  FLIP = 0 (forward): k = cin, n = cout, g = w[n][.][.][k].  FLIP = 1 (input gradient): k = cout, n = cin,
+// g[r][s] = w[k][2 - r][2 - s][n] (taps rotated by 180 degrees).
+template <int FLIP>
+__global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ w, float* __restrict__ u, int Kc, int Nc, int KS, int CB) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Kc * Nc) return;
+    // the fastest thread index walks the contiguous axis of w: cin = k (forward) or cin = n (input gradient)
+    const int k = FLIP ? idx / Nc : idx % Kc, n = FLIP ? idx % Nc : idx / Kc;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            g[r][s] = FLIP ? w[((size_t)(k * 3 + (2 - r)) * 3 + (2 - s)) * Nc + n] : w[((size_t)(n * 3 + r) * 3 + s) * Kc + k];
+    float t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        t[0][s] = g[0][s];
+        t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+        t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+        t[3][s] = g[2][s];
+    }
+    const int ks = k / KC, j = (k % KC) / 8, h = (k % 8) / 4, e = k % 4, cb = n / 32, lane = h * 32 + n % 32;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+        float v[4];
+        v[0] = t[xi][0];
+        v[1] = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]);
+        v[2] = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]);
+        v[3] = t[xi][2];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            const int p = xi * 4 + nu;
+            u[((((size_t)(p * KS + ks) * CB + cb) * 2 + j) * 64 + lane) * 4 + e] = v[nu];
+        }
+    }
+}
+
+// XF: fused input activation. EPI: 0 forward (+ statistics when p.pmean), 1 input gradient with the in-block fused epilogue.
+// ODD: some tile slots hold pixels outside the image (odd H / W) or past the last tile — their outputs are masked out of the sums.
+template <bool XF, int EPI, bool ODD>
+__global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
+    __shared__ __attribute__((aligned(16))) float sV[2 * 16 * 64 * KC];   // 128 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(p.u, p.u_bytes);
+    const int NB = ((p.MT + 7) / 8) * 8 * p.NT, G = gridDim.x;
+    const int ltile = tid >> 2, q = tid & 3;
+    const int ntile = 32 * wn + (lane & 31), hh = lane >> 5;
+    const int THW = p.TH * p.TW;
+
+    int bid = blockIdx.x, mt = 0, nt = 0;
+    while (bid < NB && !unit_of_block(bid, p.MT, p.NT, mt, nt)) bid += G;
+    if (bid >= NB) return;
+
+    uint32_t off[16];
+    unsigned long long okm[16];      // lane masks of the valid patch pixels (v_cndmask's scalar operand; fused activation only)
+    uint32_t po[4], po_next[4];      // byte offsets of this lane's four output pixels (+ channel base), current / next unit
+    uint32_t ua, ua_next;            // byte offset of this lane's U fragments inside a (position, slice) block: (channel block, lane)
+    int cur_mt = mt, cur_nt = nt;
+    // everything that depends on the unit: loader offsets + masks, epilogue offsets, U fragment base
+    auto setup = [&](int mt_, int nt_, bool live, uint32_t (&po_)[4], uint32_t& ua_) {
+        {
+            const int t = mt_ * 64 + ltile;
+            const int b = t / THW, rem = t - b * THW, th = rem / p.TW, tw = rem - th * p.TW;
+            const uint32_t base = (uint32_t)((((b * p.H + 2 * th - 1) * p.W + 2 * tw - 1) * p.Kc + q * 4) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int yy = 2 * th - 1 + i, xx = 2 * tw - 1 + j;
+                    const bool ok = live && t < p.T && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                    off[i * 4 + j] = ok ? base + (uint32_t)((i * p.W + j) * p.Kc * 4) : OOB;
+                    if constexpr (XF) okm[i * 4 + j] = __builtin_amdgcn_ballot_w64(ok);
+                }
+        }
+        {
+            const int t = mt_ * 64 + ntile;
+            const int b = t / THW, rem = t - b * THW, th = rem / p.TW, tw = rem - th * p.TW;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int yy = 2 * th + i, xx = 2 * tw + j;
+                    const bool ok = live && t < p.T && yy < p.H && xx < p.W;
+                    po_[i * 2 + j] = ok ? (uint32_t)((((b * p.H + yy) * p.W + xx) * p.Nc + 64 * nt_ + 32 * wm + 4 * hh) * 4) : OOB;
+                }
+        }
+        ua_ = (uint32_t)(((2 * nt_ + wm) * 2 * 64 + lane) * 16);       // + ((pos * KS + ks) * CB) * 2048 + j * 1024 bytes
+    };
+    setup(mt, nt, true, po, ua);
+    float* const wbase = sV + ltile * KC + 4 * (q ^ ((ltile >> 2) & 3));              // + buf * 16384 + pos * 1024
+    const float* const rb0 = sV + ntile * KC + 4 * ((0 + hh) ^ ((ntile >> 2) & 3));   // chunk of MFMAs j = 0
+    const float* const rb1 = sV + ntile * KC + 4 * ((2 + hh) ^ ((ntile >> 2) & 3));   // chunk of MFMAs j = 1
+    const uint32_t ustep = (uint32_t)p.CB * 2048;      // bytes per (position, slice) block of U
+
+    f32x16 acc[16];
+    f32x4 xr[16];
+    auto load_x = [&](int ks) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xr[k] = bld4(rx, off[k], (uint32_t)ks * (KC * 4));
+    };
+    // activation (+ padding select) and column transform of patch column j. asm: IR passes otherwise regroup these scalar ops (SLP packs
+    // them into v_pk_*, an anti-lever beside MFMAs, and sinks the selects to their users) whatever the machine scheduler is told.
+    auto act_col = [&](int j, const f32x4& sc4, const f32x4& sh4) {
+        if constexpr (XF) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_max_f32 %0, 0, %0\n\tv_cndmask_b32 %0, 0, %0, %3"
+                                 : "+v"(xr[i * 4 + j][e]) : "v"(sc4[e]), "v"(sh4[e]), "s"(okm[i * 4 + j]));
+        }
+        const f32x4 d0 = xr[j], d1 = xr[4 + j], d2 = xr[8 + j], d3 = xr[12 + j];
+        xr[j] = d0 - d2; xr[4 + j] = d1 + d2; xr[8 + j] = d2 - d1; xr[12 + j] = d1 - d3;
+    };
+    // row transform of patch row i and its four LDS stores
+    auto row_store = [&](int i, int buf) {
+        const f32x4 t0 = xr[i * 4], t1 = xr[i * 4 + 1], t2 = xr[i * 4 + 2], t3 = xr[i * 4 + 3];
+        float* w = wbase + buf * (16 * 64 * KC) + (i * 4) * (64 * KC);
+        *reinterpret_cast<f32x4*>(w) = t0 - t2;
+        *reinterpret_cast<f32x4*>(w + 64 * KC) = t1 + t2;
+        *reinterpret_cast<f32x4*>(w + 2 * 64 * KC) = t2 - t1;
+        *reinterpret_cast<f32x4*>(w + 3 * 64 * KC) = t1 - t3;
+    };
+    auto ld_scale = [&](int ks, f32x4& sc4, f32x4& sh4) {
+        if constexpr (XF) {
+            sc4 = ld4(p.sc + ks * KC + 4 * q);
+            sh4 = ld4(p.sh + ks * KC + 4 * q);
+        }
+    };
+
+    // prologue (first unit of this workgroup only): slice 0 into buffer 0
+    f32x4 sc4 = {1, 1, 1, 1}, sh4 = {0, 0, 0, 0};
+    load_x(0);
+    ld_scale(0, sc4, sh4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) act_col(j, sc4, sh4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row_store(i, 0);
+
+    // U fragment ring: slot (pos % 16), loaded PF positions ahead across slice AND unit boundaries
+    f32x4 a[16][2];
+    auto load_u = [&](int pos, uint32_t base, int ks) {
+        const uint32_t soff = (uint32_t)(pos * p.KS + ks) * ustep;      // uniform: the scalar offset of the buffer load
+        a[pos][0] = bld4(ru, base, soff);
+        a[pos][1] = bld4(ru, base + 1024u, soff);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load_u(i, ua, 0);
+    __syncthreads();
+
+    int buf = 0;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        bool more = false;
+        for (int ks = 0; ks < p.KS; ++ks) {
+            const bool last = ks + 1 == p.KS;
+            int ksn = ks + 1;
+            uint32_t uan = ua;
+            if (last) {      // uniform: the next unit of this workgroup (or a dead one: every offset out of range) — no loads in here
+                int nb = bid + G, mt2 = 0, nt2 = 0;
+                while (nb < NB && !unit_of_block(nb, p.MT, p.NT, mt2, nt2)) nb += G;
+                more = nb < NB;
+                bid = nb;
+                cur_mt = mt; cur_nt = nt;
+                mt = mt2; nt = nt2;
+                setup(mt2, nt2, more, po_next, ua_next);
+                ksn = 0;
+                uan = more ? ua_next : ua;
+            }
+            load_x(ksn);
+            ld_scale(ksn, sc4, sh4);
+            const float* r0 = rb0 + buf * (16 * 64 * KC);
+            const float* r1 = rb1 + buf * (16 * 64 * KC);
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(r0), b1 = *reinterpret_cast<const f32x4*>(r1);
+            __builtin_amdgcn_sched_barrier(0);
+            auto position = [&](auto POSC) {
+                constexpr int pos = decltype(POSC)::value;
+                if (pos + PF < 16) load_u(pos + PF, ua, ks);
+                else load_u(pos + PF - 16, uan, ksn);
+                f32x4 nb0 = b0, nb1 = b1;
+                if (pos < 15) {
+                    nb0 = *reinterpret_cast<const f32x4*>(r0 + (pos + 1) * (64 * KC));
+                    nb1 = *reinterpret_cast<const f32x4*>(r1 + (pos + 1) * (64 * KC));
+                }
+                const f32x4 a0 = a[pos][0], a1 = a[pos][1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[pos], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[pos], 0, 0, 0);
+                if constexpr (pos >= 8 && pos < 12) act_col(pos - 8, sc4, sh4);
+                if constexpr (pos >= 12) row_store(pos - 12, buf ^ 1);
+                b0 = nb0; b1 = nb1;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for_each_const(position, std::make_integer_sequence<int, 16>{});
+            __syncthreads();
+            buf ^= 1;
+        }
+
+        // ---- epilogue: Y = A^T M A per (tile, channel); per lane 4 pixels x 4 quads of 4 consecutive channels ------------------------
+        const int ch0 = 64 * cur_nt + 32 * wm + 4 * hh;                                  // + 8 g: first channel of quad g
+        const int part = cur_mt * 4 + 2 * wn + ((lane >> 4) & 1);                        // this lane's 16-tile statistics group
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                float s[2][4];
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) {
+                    const float m0 = acc[nu][r], m1 = acc[4 + nu][r], m2 = acc[8 + nu][r], m3 = acc[12 + nu][r];
+                    s[0][nu] = m0 + m1 + m2;
+                    s[1][nu] = m1 - m2 - m3;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    o[i * 2][e] = s[i][0] + s[i][1] + s[i][2];
+                    o[i * 2 + 1][e] = s[i][1] - s[i][2] - s[i][3];
+                }
+            }
+            if constexpr (EPI == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bst4(ry, o[k], po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+                if (p.pmean) {
+                    // (mean, M2) of the group's valid pixels per channel: sum -> mean -> sum of squared deviations, every reduction a
+                    // fixed-order DPP row sum. Slots outside the image (ODD) are zeroed and their (0 - mean)^2 taken back out.
+                    f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if constexpr (ODD) { if (po[k] == OOB) o[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                        s1 += o[k];
+                    }
+                    f32x4 mean, m2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mean[e] = row16_sum(s1[e]) * p.rcnt;
+                    f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 dlt = o[k] - mean;
+                        s2 += dlt * dlt;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        m2[e] = row16_sum(s2[e]);
+                        if constexpr (ODD) m2[e] -= (64.f - p.cnt) * mean[e] * mean[e];
+                    }
+                    if ((lane & 15) == 0 && part < p.P) {
+                        *reinterpret_cast<f32x4*>(p.pmean + (size_t)part * p.Nc + ch0 + 8 * g) = mean;
+                        *reinterpret_cast<f32x4*>(p.pm2 + (size_t)part * p.Nc + ch0 + 8 * g) = m2;
+                    }
+                }
+            } else {
+                // in-block fused input gradient: g = gate . acc, gate = fma(y0, scale0, shift0) > 0 (the forward loader's own expression),
+                // sums of g and g * xhat0 per 64 pixels for the BatchNorm backward of the producer
+                const __amdgpu_buffer_rsrc_t r0y = make_rsrc(p.ey0, p.y_bytes);
+                f32x4 y0[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y0[k] = bld4(r0y, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+                const f32x4 esc = ld4(p.escale0 + ch0 + 8 * g), esh = ld4(p.eshift0 + ch0 + 8 * g);
+                const f32x4 emu = ld4(p.emean0 + ch0 + 8 * g), einv = ld4(p.einv0 + ch0 + 8 * g);
+                f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f32x4 gv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bool on = __builtin_fmaf(y0[k][e], esc[e], esh[e]) > 0.f;
+                        if constexpr (ODD) on = on && po[k] != OOB;
+                        gv[e] = on ? o[k][e] : 0.f;
+                        sg[e] += gv[e];
+                        sgx[e] += gv[e] * ((y0[k][e] - emu[e]) * einv[e]);
+                    }
+                    bst4(ry, gv, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+                }
+                if (p.esum) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sg[e] = row16_sum(sg[e]); sgx[e] = row16_sum(sgx[e]); }
+                    if ((lane & 15) == 0 && part < p.P) {
+                        *reinterpret_cast<f32x4*>(p.esum + (size_t)part * p.Nc + ch0 + 8 * g) = sg;
+                        *reinterpret_cast<f32x4*>(p.esum + ((size_t)p.P + part) * p.Nc + ch0 + 8 * g) = sgx;
+                    }
+                }
+            }
+        }
+        if (!more) break;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) po[k] = po_next[k];
+        ua = ua_next;
+    }
+}
+
+bool wino_shape(const osi_conv_desc* d) {
+    return conv_desc_ok(d) && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->H == d->Ho && d->W == d->Wo && d->H >= 2 && d->W >= 2;
+}
+
+struct Geo { int TH, TW, T, MT, P; bool odd; float cnt; bool uniform; };
+Geo geo_of(const osi_conv_desc* d) {
+    Geo g{};
+    g.TH = (d->H + 1) / 2; g.TW = (d->W + 1) / 2; g.T = d->B * g.TH * g.TW; g.MT = (g.T + 63) / 64; g.P = (g.T + 15) / 16;
+    const bool even = d->H % 2 == 0 && d->W % 2 == 0;
+    g.odd = !even || g.T % 64 != 0;
+    // every 16-tile statistics group holds the same number of valid pixels: all groups full and either all tiles inside the image or a
+    // group = whole images; or there is only one group (then it holds every pixel)
+    const int thw = g.TH * g.TW;
+    if (g.P == 1) { g.uniform = true; g.cnt = (float)((long)d->B * d->H * d->W); }
+    else if (g.T % 16 == 0 && even) { g.uniform = true; g.cnt = 64.f; }
+    else if (g.T % 16 == 0 && 16 % thw == 0) { g.uniform = true; g.cnt = (float)(16 / thw * d->H * d->W); }
+    else { g.uniform = false; g.cnt = 64.f; }
+    return g;
+}
+
+template <int FLIP>
+int launch_weights(const float* w, float* u, int Kc, int Nc, hipStream_t st) {
+    hipLaunchKernelGGL(k_wino_weights<FLIP>, dim3((unsigned)((Kc * Nc + 255) / 256)), dim3(256), 0, st, w, u, Kc, Nc, Kc / KC, Nc / 32);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+WinoP make_wp(const osi_conv_desc* d, const Geo& g, int Kc, int Nc) {
+    WinoP p{};
+    p.H = d->H; p.W = d->W; p.Kc = Kc; p.Nc = Nc; p.TH = g.TH; p.TW = g.TW; p.T = g.T; p.KS = Kc / KC; p.CB = Nc / 32; p.MT = g.MT; p.NT = Nc / 64;
+    p.x_bytes = (int)((size_t)d->B * d->H * d->W * Kc * 4);
+    p.y_bytes = (int)((size_t)d->B * d->H * d->W * Nc * 4);
+    p.u_bytes = (int)((size_t)16 * Kc * Nc * 4);
+    p.P = g.P; p.cnt = g.cnt; p.rcnt = 1.f / g.cnt;
+    return p;
+}
+
+int wino_grid(const WinoP& p) {
+    const int nb = ((p.MT + 7) / 8) * 8 * p.NT;
+    int cus = chip_cus() / 8 * 8;       // the persistent stride keeps blockIdx % 8 (the XCD) of a workgroup's units
+    if (cus < 8) cus = 8;
+    return nb < cus ? nb : cus;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* 1 when the Winograd form takes this convolution (3x3 / stride 1 / pad 1, Cin % 16 == 0 and Cout % 64 == 0 forward — the roles swap for
+ * the input gradient —, every BatchNorm statistics group of 16 tiles holding the same number of pixels). */
+int osi_conv_wino_eligible(const osi_conv_desc* d, int input_gradient) {
+    if (!wino_shape(d)) return 0;
+    const int Kc = input_gradient ? d->Cout : d->Cin, Nc = input_gradient ? d->Cin : d->Cout;
+    if (Kc % KC || Nc % 64) return 0;
+    const Geo g = geo_of(d);
+    return (input_gradient || g.uniform) ? 1 : 0;
+}
+
+/* bytes of the transformed-weight buffer (16 positions x Cin x Cout floats) both forms need; 0 = not eligible */
+size_t osi_conv_wino_workspace(const osi_conv_desc* d) {
+    if (!wino_shape(d)) return 0;
+    return (size_t)16 * d->Cin * d->Cout * sizeof(float);
+}
+
+/* Winograd twin of osi_conv_fwd_act / osi_conv_fwd_bnstats: in_scale / in_shift may be NULL (plain input). P = ceil(tiles / 16),
+ * rows_per_block = valid pixels of a 16-tile group (64 for even H, W). pstats needs 2 * P * Cout floats. */
+int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
+                      void* ws, size_t ws_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream) {
+    OSI_REQUIRE(x && w && y && ws && osi_conv_wino_eligible(d, 0));
+    OSI_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
+    OSI_REQUIRE(ws_bytes >= osi_conv_wino_workspace(d));
+    OSI_REQUIRE(!pstats || (P && rows_per_block));
+    hipStream_t st = (hipStream_t)stream;
+    const Geo g = geo_of(d);
+    WinoP p = make_wp(d, g, d->Cin, d->Cout);
+    p.x = x; p.u = (const float*)ws; p.y = y; p.sc = in_scale; p.sh = in_shift;
+    if (pstats) {
+        OSI_REQUIRE(pstats_bytes >= (size_t)2 * g.P * d->Cout * sizeof(float));
+        p.pmean = pstats; p.pm2 = pstats + (size_t)g.P * d->Cout;
+        *P = g.P; *rows_per_block = (int)g.cnt;
+    }
+    if (int e = launch_weights<0>(w, (float*)ws, d->Cin, d->Cout, st)) return e;
+    const dim3 grid((unsigned)wino_grid(p)), blk(256);
+    if (in_scale) {
+        if (g.odd) hipLaunchKernelGGL((k_wino<true, 0, true>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((k_wino<true, 0, false>), grid, blk, 0, st, p);
+    } else {
+        if (g.odd) hipLaunchKernelGGL((k_wino<false, 0, true>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((k_wino<false, 0, false>), grid, blk, 0, st, p);
+    }
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+/* Winograd twin of osi_conv_dgrad_fused for the executor's "in-block" fusion only: no addend, no stored bitmask, one consumer, no pool
+ * mode; gate recomputed from f->y0 (scale0 / shift0 required), partial sums optional. P = ceil(tiles / 16) groups of <= 64 pixels. */
+int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const osi_dgrad_fusion* f, void* ws,
+                              size_t ws_bytes, int* P, osi_stream_t stream) {
+    OSI_REQUIRE(dy && w && dx && ws && f && P && osi_conv_wino_eligible(d, 1));
+    OSI_REQUIRE(!f->relu_mask && !f->y1 && !f->pool_idx && f->addend_stride != 2);
+    OSI_REQUIRE(f->y0 && f->scale0 && f->shift0);
+    OSI_REQUIRE(!f->partials || (f->mean0 && f->invstd0));
+    OSI_REQUIRE(ws_bytes >= osi_conv_wino_workspace(d));
+    hipStream_t st = (hipStream_t)stream;
+    const Geo g = geo_of(d);
+    WinoP p = make_wp(d, g, d->Cout, d->Cin);
+    p.x = dy; p.u = (const float*)ws; p.y = dx;
+    p.ey0 = f->y0; p.escale0 = f->scale0; p.eshift0 = f->shift0;
+    // without partial sums the epilogue still evaluates xhat: any readable per-channel vectors do
+    p.emean0 = f->mean0 ? f->mean0 : f->scale0; p.einv0 = f->invstd0 ? f->invstd0 : f->scale0;
+    if (f->partials) {
+        OSI_REQUIRE(f->partials_bytes >= (size_t)3 * g.P * d->Cin * sizeof(float));
+        p.esum = f->partials;
+    }
+    *P = g.P;
+    if (int e = launch_weights<1>(w, (float*)ws, d->Cout, d->Cin, st)) return e;
+    const dim3 grid((unsigned)wino_grid(p)), blk(256);
+    if (g.odd) hipLaunchKernelGGL((k_wino<false, 1, true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((k_wino<false, 1, false>), grid, blk, 0, st, p);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+}  // extern "C"

@@ -44,6 +44,8 @@ struct OsiTuning {
     int fwd_rows;         // fwd: 1x1 stride-1 convolutions with Cin = 64 / 128 on the persistent row walker (k_conv1x1_rows): 0 off, 1 Cin = 64 at >= 8 row tiles per CU, 2 every eligible shape (tests)
     int fwd_w3;           // fwd: 3x3 stride-1 convolutions stage one activation window per tap row (k_conv_fwd W3): 0 off, 1 on
     int dgrad_w3;         // dgrad: the same for the in-block fused 3x3 stride-1 input gradients (k_conv_dgrad W3): 0 off, 1 on
+    int fwd_wino;         // fwd: the executor runs its 3x3 stride-1 convolutions in the Winograd F(2x2,3x3) form (conv_wino.hip): 0 off, 1 on
+    int dgrad_wino;       // dgrad: the same for the in-block fused 3x3 stride-1 input gradients
     int dp_reserved_cus;  // CUs' worth of wave slots the launch plans leave to co-resident communication kernels (data parallel); 0 = none
 };
 extern OsiTuning g_osi_tuning;

@@ -80,6 +80,7 @@ struct osi_resnet50 {
     size_t x4, wpack, gpack, a_pool, pool_idx, pooled, feat, logits_ws;
     size_t bn_ws, bn_ws2, bn_ws_bytes, wg_ws, wg_ws_bytes, dg_ws, dg_ws_bytes;   // bn_ws2: BatchNorm scratch of the side-stream branch
     size_t stem_ws = 0, stem_ws_bytes = 0;
+    size_t wino_ws = 0, wino_ws_bytes = 0;   // transformed weights of the Winograd forms (main stream only: forward conv2, in-block input gradients)
     static constexpr int NSCR = 12;   // scratch activations-gradient buffers (each = largest activation)
     size_t scratch[NSCR], scratch_floats;
     size_t dfeat, dpooled;
@@ -195,7 +196,7 @@ struct osi_resnet50 {
         return plan_hw_cus == device_cus() && a.wgrad_tile == b.wgrad_tile && a.wgrad_blocks == b.wgrad_blocks && a.wgrad3 == b.wgrad3 && a.wgrad3_blocks == b.wgrad3_blocks &&
                a.tail_split == b.tail_split && a.tail_cus == b.tail_cus && a.tail_smax == b.tail_smax && a.tail_mint == b.tail_mint &&
                a.tail_gain == b.tail_gain && a.tail_qmax == b.tail_qmax && a.stem_direct == b.stem_direct && a.wgrad_group == b.wgrad_group &&
-               a.dp_reserved_cus == b.dp_reserved_cus;
+               a.dp_reserved_cus == b.dp_reserved_cus && a.fwd_wino == b.fwd_wino && a.dgrad_wino == b.dgrad_wino;
     }
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wdone = nullptr, ev_rmain = nullptr, ev_rside = nullptr;
@@ -305,7 +306,7 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
     n->dfeat = n->ws_alloc((size_t)B * fc_dim);
     n->dpooled = n->ws_alloc((size_t)B * 2048);
     // scratch sizing
-    size_t maxact = 0, bnws = 0, wgws = 0, dgws = 0;
+    size_t maxact = 0, bnws = 0, wgws = 0, dgws = 0, winows = 0;
     for (auto& c : n->convs) {
         size_t e = (size_t)c.d.B * c.d.Ho * c.d.Wo * c.d.Cout;
         if (e > maxact) maxact = e;
@@ -321,7 +322,18 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
         wg = osi_stem_wgrad_direct_workspace(&c.d);
         if (wg > wgws) wgws = wg;
         if (!(c.d.Cin == 4 && c.d.R == 7)) { size_t dg = osi_conv_dgrad_fused_workspace(&c.d); if (dg > dgws) dgws = dg; }
+        if (osi_conv_wino_eligible(&c.d, 0) || osi_conv_wino_eligible(&c.d, 1)) {
+            // Winograd forms: one (mean, M2) / (sum g, sum g xhat) partial per 16 tiles (+ the merge scratch behind the statistics)
+            const size_t Pw = ((size_t)c.d.B * ((c.d.H + 1) / 2) * ((c.d.W + 1) / 2) + 15) / 16;
+            size_t w = osi_conv_wino_workspace(&c.d);
+            if (w > winows) winows = w;
+            w = (2 * Pw + 64) * c.d.Cout * sizeof(float);
+            if (w > bnws) bnws = w;
+            w = 3 * Pw * c.d.Cin * sizeof(float);
+            if (w > dgws) dgws = w;
+        }
     }
+    n->wino_ws_bytes = winows; n->wino_ws = n->ws_alloc(winows / 4 + 4);
     n->bn_ws_bytes = bnws; n->bn_ws = n->ws_alloc(bnws / 4 + 4); n->bn_ws2 = n->ws_alloc(bnws / 4 + 4);
     n->wg_ws_bytes = wgws; n->wg_ws = n->ws_alloc(wgws / 4 + 4);
     // the fused stem weight gradient has its own slab: it may run on the main stream while the side stream still owns wg_ws
@@ -430,10 +442,13 @@ static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buff
     BN& b = n->bns[c.bn];
     const float* isc = in_bn >= 0 ? ws + n->bns[in_bn].scale : nullptr;
     const float* ish = in_bn >= 0 ? ws + n->bns[in_bn].shift : nullptr;
+    // 3x3 / stride 1 (conv2 of a bottleneck without a stride): Winograd F(2x2,3x3), 2.25x fewer multiplies (csrc/conv_wino.hip); main stream only
+    const bool wino = n->plan_knobs.fwd_wino && isc && !in_res && st != n->side && osi_conv_wino_eligible(&c.d, 0);
     if (training) {
         // batch statistics come out of the conv epilogue (per row tile), only a tiny per-channel merge follows
         int P = 0, rows = 0;
         if (isc && in_res) OSI_TRY(osi_conv_fwd_act2(&c.d, x, isc, ish, in_res, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
+        else if (isc && wino) OSI_TRY(osi_conv_fwd_wino(&c.d, x, isc, ish, w, ws + c.y, ws + n->wino_ws, n->wino_ws_bytes, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
         else if (isc) OSI_TRY(osi_conv_fwd_act(&c.d, x, isc, ish, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
         else OSI_TRY(osi_conv_fwd_bnstats(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
         OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
@@ -442,6 +457,7 @@ static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buff
                                       ws + b.shift, st));
     } else {
         if (isc && in_res) OSI_TRY(osi_conv_fwd_act2(&c.d, x, isc, ish, in_res, w, ws + c.y, OSI_TILE_AUTO, nullptr, 0, nullptr, nullptr, st));
+        else if (isc && wino) OSI_TRY(osi_conv_fwd_wino(&c.d, x, isc, ish, w, ws + c.y, ws + n->wino_ws, n->wino_ws_bytes, nullptr, 0, nullptr, nullptr, st));
         else if (isc) OSI_TRY(osi_conv_fwd_act(&c.d, x, isc, ish, w, ws + c.y, OSI_TILE_AUTO, nullptr, 0, nullptr, nullptr, st));
         else OSI_TRY(osi_conv_fwd(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, st));
         OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
@@ -695,6 +711,11 @@ static int dgrad_fused(osi_resnet50* n, int ci, const float* params, float* ws, 
     f.addend_stride = add_even ? 2 : 1;
     int P = 0;
     OSI_TRY(before_dgrad(n, st));
+    // the in-block 3x3 / stride 1 input gradients (gate recomputed, one consumer, no addend) take the Winograd form
+    if (n->plan_knobs.dgrad_wino && f.scale0 && pd < 0 && addi < 0 && osi_conv_wino_eligible(&c.d, 1))
+        OSI_TRY(osi_conv_dgrad_fused_wino(&c.d, ws + n->scratch[dyi], params + c.w_off, ws + n->scratch[dxi], &f, ws + n->wino_ws,
+                                          n->wino_ws_bytes, &P, st));
+    else
     OSI_TRY(osi_conv_dgrad_fused(&c.d, ws + n->scratch[dyi], params + c.w_off, ws + n->scratch[dxi],
                                  addi >= 0 ? ws + n->scratch[addi] : nullptr, &f, OSI_TILE_AUTO, &P, st));
     n->fused_P = P;

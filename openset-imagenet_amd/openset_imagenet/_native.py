@@ -42,6 +42,10 @@ _SIGS = {
     "osi_conv_fwd_act": (c_int, [_PD, P, P, P, P, P, c_int, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
     "osi_conv_fwd_act2": (c_int, [_PD, P, P, P, P, P, P, c_int, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
     "osi_conv_wgrad_act": (c_int, [_PD, P, P, P, P, P, P, c_size_t, P]),
+    "osi_conv_wino_eligible": (c_int, [_PD, c_int]),
+    "osi_conv_wino_workspace": (c_size_t, [_PD]),
+    "osi_conv_fwd_wino": (c_int, [_PD, P, P, P, P, P, P, c_size_t, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
+    "osi_conv_dgrad_fused_wino": (c_int, [_PD, P, P, P, P, P, c_size_t, POINTER(c_int), P]),
     "osi_conv_fwd_bnstats_workspace": (c_size_t, [_PD]),
     "osi_conv_fwd_bnstats": (c_int, [_PD, P, P, P, c_int, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
     "osi_bn_finalize_stats": (c_int, [P, c_size_t, c_int, c_int, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P]),
@@ -153,7 +157,7 @@ def lib():
         _lib = handle
         # development A/B switches: the environment is read HERE, once, and handed to the library explicitly
         for env, knob in (("OSI_WGRAD_TILE", b"wgrad_tile"), ("OSI_WGRAD_BLOCKS", b"wgrad_blocks"), ("OSI_WGRAD_NST", b"wgrad_nst"),
-                          ("OSI_WGRAD_GROUP", b"wgrad_group"), ("OSI_BN_GRID", b"bn_grid"), ("OSI_BN_GRID_BWD", b"bn_grid_bwd"), ("OSI_BN_SINGLE_P", b"bn_single_p"), ("OSI_BN_WIDE_P", b"bn_wide_p"), ("OSI_TAIL_GAIN", b"tail_gain"), ("OSI_TAIL_QMAX", b"tail_qmax"), ("OSI_WGRAD3", b"wgrad3"), ("OSI_WGRAD3_BLOCKS", b"wgrad3_blocks"), ("OSI_FWD_WIDE", b"fwd_wide"), ("OSI_DGRAD_WIDE", b"dgrad_wide"), ("OSI_TAIL_SPLIT", b"tail_split"), ("OSI_TAIL_CUS", b"tail_cus"), ("OSI_TAIL_SMAX", b"tail_smax"), ("OSI_TAIL_MINT", b"tail_mint"), ("OSI_STEM_DIRECT", b"stem_direct"), ("OSI_DP_RESERVED_CUS", b"dp_reserved_cus"), ("OSI_FWD_ROWS", b"fwd_rows"), ("OSI_FWD_W3", b"fwd_w3"), ("OSI_DGRAD_W3", b"dgrad_w3")):
+                          ("OSI_WGRAD_GROUP", b"wgrad_group"), ("OSI_BN_GRID", b"bn_grid"), ("OSI_BN_GRID_BWD", b"bn_grid_bwd"), ("OSI_BN_SINGLE_P", b"bn_single_p"), ("OSI_BN_WIDE_P", b"bn_wide_p"), ("OSI_TAIL_GAIN", b"tail_gain"), ("OSI_TAIL_QMAX", b"tail_qmax"), ("OSI_WGRAD3", b"wgrad3"), ("OSI_WGRAD3_BLOCKS", b"wgrad3_blocks"), ("OSI_FWD_WIDE", b"fwd_wide"), ("OSI_DGRAD_WIDE", b"dgrad_wide"), ("OSI_TAIL_SPLIT", b"tail_split"), ("OSI_TAIL_CUS", b"tail_cus"), ("OSI_TAIL_SMAX", b"tail_smax"), ("OSI_TAIL_MINT", b"tail_mint"), ("OSI_STEM_DIRECT", b"stem_direct"), ("OSI_DP_RESERVED_CUS", b"dp_reserved_cus"), ("OSI_FWD_ROWS", b"fwd_rows"), ("OSI_FWD_W3", b"fwd_w3"), ("OSI_DGRAD_W3", b"dgrad_w3"), ("OSI_FWD_WINO", b"fwd_wino"), ("OSI_DGRAD_WINO", b"dgrad_wino")):
             if os.environ.get(env):
                 check(handle.osi_set_tuning(knob, int(os.environ[env])), f"osi_set_tuning({knob.decode()})")
     return _lib
