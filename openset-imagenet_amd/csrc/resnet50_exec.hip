@@ -443,7 +443,7 @@ static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buff
     const float* isc = in_bn >= 0 ? ws + n->bns[in_bn].scale : nullptr;
     const float* ish = in_bn >= 0 ? ws + n->bns[in_bn].shift : nullptr;
     // 3x3 / stride 1 (conv2 of a bottleneck without a stride): Winograd F(2x2,3x3), 2.25x fewer multiplies (csrc/conv_wino.hip); main stream only
-    const bool wino = n->plan_knobs.fwd_wino && isc && !in_res && st != n->side && osi_conv_wino_eligible(&c.d, 0);
+    const bool wino = n->plan_knobs.fwd_wino && isc && !in_res && (n->side == nullptr || st != n->side) && osi_conv_wino_eligible(&c.d, 0);
     if (training) {
         // batch statistics come out of the conv epilogue (per row tile), only a tiny per-channel merge follows
         int P = 0, rows = 0;
