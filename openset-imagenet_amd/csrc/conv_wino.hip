@@ -56,18 +56,15 @@ struct WinoP {
     const float* ey0;    // producer's pre-BN tensor, same shape as y
     const float *escale0, *eshift0, *emean0, *einv0;
     float* esum;         // [3][P][Nc]: sum g, sum g * xhat0 (third plane unused)
+    // work decomposition: q full rounds of whole units, r remainder units cut along K into G pieces (slab: 2 slots of 64 KiB per workgroup)
+    int q, r;
+    float* slab;
+    int slab_bytes;
 };
 
 template <class F, int... I>
 __device__ __forceinline__ void for_each_const(F& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
-}
-
-__device__ __forceinline__ bool unit_of_block(int bid, int MT, int NT, int& mt, int& nt) {
-    const int xcd = bid & 7, slot = bid >> 3;      // all NT column units of a tile block on one XCD's L2
-    nt = slot % NT;
-    mt = (slot / NT) * 8 + xcd;
-    return mt < MT;
 }
 
 // sum over the 16 lanes of a DPP row (= 16 tiles = one statistics group), result in every lane of the row
@@ -120,6 +117,142 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
     }
 }
 
+// ---- work decomposition ------------------------------------------------------------------------------------------------------------
+// V = MT x NT units in an XCD-friendly linear order (the NT column units of a tile block consecutive on one XCD: workgroup w and its units
+// w + k G share blockIdx % 8). One workgroup per CU (G of them) would leave the last of ceil(V / G) rounds ragged — at 1.53 / 3.06 / 6.125
+// units per CU (the 14x14 / 28x28 / 56x56 layers at batch 128) that is 23 / 23 / 12 % of the launch. So only the q = V / G FULL rounds run
+// as whole units (phase 1: unit v = w + k G, ordinary epilogue); the r = V - q G remaining units are cut STREAM-K style: their r x KS
+// K slices form one line that is dealt to the G workgroups in equal contiguous pieces (phase 2: workgroup w takes slices
+// [w r KS / G, (w + 1) r KS / G), at most two units touched), each piece's output-transformed partial tile goes to a slab slot
+// (w, first / second unit) in the per-lane register order, and k_wino_fixup adds a unit's pieces in workgroup order — fixed, so the result
+// is bitwise reproducible — and runs the same epilogue code. The software pipeline crosses unit, phase and piece boundaries.
+struct Seg { int v, ks0, ks1, slot; bool valid; };     // unit, K-slice range [ks0, ks1), slab slot (-1: a whole unit, ordinary epilogue)
+
+__device__ __forceinline__ void unit_of(int v, int MT, int NT, int& mt, int& nt) {
+    const int full = (MT / 8) * 8 * NT;                // units of the complete groups of 8 tile blocks
+    if (v < full) {
+        const int xcd = v & 7, slot = v >> 3;
+        nt = slot % NT;
+        mt = (slot / NT) * 8 + xcd;
+    } else {
+        const int rem = MT & 7, vv = v - full;         // the last (MT % 8) tile blocks: tile block fastest
+        mt = (MT / 8) * 8 + vv % rem;
+        nt = vv / rem;
+    }
+}
+__device__ __forceinline__ int piece_begin(int w, int r, int KS, int G) { return (int)(((long)w * r * KS) / G); }
+
+// first segment of workgroup w / the one after `c` (valid = false: nothing left)
+__device__ __forceinline__ Seg seg_phase2(int w, int q, int r, int KS, int G, bool second, int first_u) {
+    Seg s{0, 0, 0, -1, false};
+    if (r == 0) return s;
+    const int b0 = piece_begin(w, r, KS, G), b1 = piece_begin(w + 1, r, KS, G);
+    if (b1 <= b0) return s;
+    const int u0 = b0 / KS;
+    if (!second) {
+        s.v = q * G + u0; s.ks0 = b0 - u0 * KS; s.ks1 = min(KS, s.ks0 + (b1 - b0)); s.slot = 0; s.valid = true;
+        return s;
+    }
+    if (b1 > (u0 + 1) * KS) { s.v = q * G + u0 + 1; s.ks0 = 0; s.ks1 = b1 - (u0 + 1) * KS; s.slot = 1; s.valid = true; }
+    return s;
+}
+__device__ __forceinline__ Seg seg_first(int w, int q, int r, int KS, int G) {
+    if (q > 0) return Seg{w, 0, KS, -1, true};
+    return seg_phase2(w, q, r, KS, G, false, 0);
+}
+__device__ __forceinline__ Seg seg_next(const Seg& c, int w, int q, int r, int KS, int G) {
+    if (c.slot < 0) {                                   // phase 1
+        if (c.v + G < q * G) return Seg{c.v + G, 0, KS, -1, true};
+        return seg_phase2(w, q, r, KS, G, false, 0);
+    }
+    if (c.slot == 0) return seg_phase2(w, q, r, KS, G, true, 0);
+    return Seg{0, 0, 0, -1, false};
+}
+
+// ---- epilogue of one channel quad (4 pixels x 4 consecutive channels of this lane's tile), shared by k_wino and k_wino_fixup -------------
+// EPI 0 forward: y + optional (mean, M2) statistics per 16 tiles; EPI 1: the in-block fused input gradient (gate, dx, sums).
+template <int EPI, bool ODD>
+__device__ __forceinline__ void epi_quad(const WinoP& p, __amdgpu_buffer_rsrc_t ry, int g, f32x4 (&o)[4], const uint32_t (&po)[4], int ch0,
+                                         int part, int lane) {
+    if constexpr (EPI == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bst4(ry, o[k], po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+        if (p.pmean) {
+            // (mean, M2) of the group's valid pixels per channel: sum -> mean -> sum of squared deviations, every reduction a fixed-order
+            // DPP row sum. Slots outside the image (ODD) are zeroed and their (0 - mean)^2 taken back out.
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (ODD) { if (po[k] == OOB) o[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                s1 += o[k];
+            }
+            f32x4 mean, m2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mean[e] = row16_sum(s1[e]) * p.rcnt;
+            f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 dlt = o[k] - mean;
+                s2 += dlt * dlt;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m2[e] = row16_sum(s2[e]);
+                if constexpr (ODD) m2[e] -= (64.f - p.cnt) * mean[e] * mean[e];
+            }
+            if ((lane & 15) == 0 && part < p.P) {
+                *reinterpret_cast<f32x4*>(p.pmean + (size_t)part * p.Nc + ch0 + 8 * g) = mean;
+                *reinterpret_cast<f32x4*>(p.pm2 + (size_t)part * p.Nc + ch0 + 8 * g) = m2;
+            }
+        }
+    } else {
+        // g = gate . acc, gate = fma(y0, scale0, shift0) > 0 (the forward loader's own expression); sums of g and g * xhat0 per 64 pixels
+        const __amdgpu_buffer_rsrc_t r0y = make_rsrc(p.ey0, p.y_bytes);
+        f32x4 y0[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y0[k] = bld4(r0y, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+        const f32x4 esc = ld4(p.escale0 + ch0 + 8 * g), esh = ld4(p.eshift0 + ch0 + 8 * g);
+        const f32x4 emu = ld4(p.emean0 + ch0 + 8 * g), einv = ld4(p.einv0 + ch0 + 8 * g);
+        f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 gv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bool on = __builtin_fmaf(y0[k][e], esc[e], esh[e]) > 0.f;
+                if constexpr (ODD) on = on && po[k] != OOB;
+                gv[e] = on ? o[k][e] : 0.f;
+                sg[e] += gv[e];
+                sgx[e] += gv[e] * ((y0[k][e] - emu[e]) * einv[e]);
+            }
+            bst4(ry, gv, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+        }
+        if (p.esum) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sg[e] = row16_sum(sg[e]); sgx[e] = row16_sum(sgx[e]); }
+            if ((lane & 15) == 0 && part < p.P) {
+                *reinterpret_cast<f32x4*>(p.esum + (size_t)part * p.Nc + ch0 + 8 * g) = sg;
+                *reinterpret_cast<f32x4*>(p.esum + ((size_t)p.P + part) * p.Nc + ch0 + 8 * g) = sgx;
+            }
+        }
+    }
+}
+
+// byte offsets of this lane's four output pixels (tile `ntile` of tile block mt, channel base of column unit nt)
+__device__ __forceinline__ void out_offsets(const WinoP& p, int mt, int nt, int ntile, int wm, int hh, bool live, uint32_t (&po)[4]) {
+    const int THW = p.TH * p.TW;
+    const int t = mt * 64 + ntile;
+    const int b = t / THW, rem = t - b * THW, th = rem / p.TW, tw = rem - th * p.TW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int yy = 2 * th + i, xx = 2 * tw + j;
+            const bool ok = live && t < p.T && yy < p.H && xx < p.W;
+            po[i * 2 + j] = ok ? (uint32_t)((((b * p.H + yy) * p.W + xx) * p.Nc + 64 * nt + 32 * wm + 4 * hh) * 4) : OOB;
+        }
+}
+
 // XF: fused input activation. EPI: 0 forward (+ statistics when p.pmean), 1 input gradient with the in-block fused epilogue.
 // ODD: some tile slots hold pixels outside the image (odd H / W) or past the last tile — their outputs are masked out of the sums.
 template <bool XF, int EPI, bool ODD>
@@ -129,20 +262,20 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, p.y_bytes);
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(p.u, p.u_bytes);
-    const int NB = ((p.MT + 7) / 8) * 8 * p.NT, G = gridDim.x;
+    const int G = gridDim.x, wg = blockIdx.x;
     const int ltile = tid >> 2, q = tid & 3;
     const int ntile = 32 * wn + (lane & 31), hh = lane >> 5;
     const int THW = p.TH * p.TW;
 
-    int bid = blockIdx.x, mt = 0, nt = 0;
-    while (bid < NB && !unit_of_block(bid, p.MT, p.NT, mt, nt)) bid += G;
-    if (bid >= NB) return;
+    Seg seg = seg_first(wg, p.q, p.r, p.KS, G);
+    if (!seg.valid) return;
+    int mt, nt;
+    unit_of(seg.v, p.MT, p.NT, mt, nt);
 
     uint32_t off[16];
     unsigned long long okm[16];      // lane masks of the valid patch pixels (v_cndmask's scalar operand; fused activation only)
     uint32_t po[4], po_next[4];      // byte offsets of this lane's four output pixels (+ channel base), current / next unit
     uint32_t ua, ua_next;            // byte offset of this lane's U fragments inside a (position, slice) block: (channel block, lane)
-    int cur_mt = mt, cur_nt = nt;
     // everything that depends on the unit: loader offsets + masks, epilogue offsets, U fragment base
     auto setup = [&](int mt_, int nt_, bool live, uint32_t (&po_)[4], uint32_t& ua_) {
         {
@@ -159,18 +292,7 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                     if constexpr (XF) okm[i * 4 + j] = __builtin_amdgcn_ballot_w64(ok);
                 }
         }
-        {
-            const int t = mt_ * 64 + ntile;
-            const int b = t / THW, rem = t - b * THW, th = rem / p.TW, tw = rem - th * p.TW;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int yy = 2 * th + i, xx = 2 * tw + j;
-                    const bool ok = live && t < p.T && yy < p.H && xx < p.W;
-                    po_[i * 2 + j] = ok ? (uint32_t)((((b * p.H + yy) * p.W + xx) * p.Nc + 64 * nt_ + 32 * wm + 4 * hh) * 4) : OOB;
-                }
-        }
+        out_offsets(p, mt_, nt_, ntile, wm, hh, live, po_);
         ua_ = (uint32_t)(((2 * nt_ + wm) * 2 * 64 + lane) * 16);       // + ((pos * KS + ks) * CB) * 2048 + j * 1024 bytes
     };
     setup(mt, nt, true, po, ua);
@@ -215,16 +337,16 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
         }
     };
 
-    // prologue (first unit of this workgroup only): slice 0 into buffer 0
+    // prologue (first segment of this workgroup only): its first slice into buffer 0
     f32x4 sc4 = {1, 1, 1, 1}, sh4 = {0, 0, 0, 0};
-    load_x(0);
-    ld_scale(0, sc4, sh4);
+    load_x(seg.ks0);
+    ld_scale(seg.ks0, sc4, sh4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) act_col(j, sc4, sh4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) row_store(i, 0);
 
-    // U fragment ring: slot (pos % 16), loaded PF positions ahead across slice AND unit boundaries
+    // U fragment ring: slot (pos % 16), loaded PF positions ahead across slice AND segment boundaries
     f32x4 a[16][2];
     auto load_u = [&](int pos, uint32_t base, int ks) {
         const uint32_t soff = (uint32_t)(pos * p.KS + ks) * ustep;      // uniform: the scalar offset of the buffer load
@@ -232,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
         a[pos][1] = bld4(ru, base + 1024u, soff);
     };
 #pragma unroll
-    for (int i = 0; i < PF; ++i) load_u(i, ua, 0);
+    for (int i = 0; i < PF; ++i) load_u(i, ua, seg.ks0);
     __syncthreads();
 
     int buf = 0;
@@ -241,21 +363,18 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
         for (int i = 0; i < 16; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        bool more = false;
-        for (int ks = 0; ks < p.KS; ++ks) {
-            const bool last = ks + 1 == p.KS;
+        Seg nxt{0, 0, 0, -1, false};
+        const int cur_mt = mt, cur_nt = nt;
+        for (int ks = seg.ks0; ks < seg.ks1; ++ks) {
+            const bool last = ks + 1 == seg.ks1;
             int ksn = ks + 1;
             uint32_t uan = ua;
-            if (last) {      // uniform: the next unit of this workgroup (or a dead one: every offset out of range) — no loads in here
-                int nb = bid + G, mt2 = 0, nt2 = 0;
-                while (nb < NB && !unit_of_block(nb, p.MT, p.NT, mt2, nt2)) nb += G;
-                more = nb < NB;
-                bid = nb;
-                cur_mt = mt; cur_nt = nt;
-                mt = mt2; nt = nt2;
-                setup(mt2, nt2, more, po_next, ua_next);
-                ksn = 0;
-                uan = more ? ua_next : ua;
+            if (last) {      // uniform: the next segment of this workgroup (or a dead one: every offset out of range) — no loads in here
+                nxt = seg_next(seg, wg, p.q, p.r, p.KS, G);
+                if (nxt.valid) unit_of(nxt.v, p.MT, p.NT, mt, nt);
+                setup(mt, nt, nxt.valid, po_next, ua_next);
+                ksn = nxt.valid ? nxt.ks0 : 0;
+                uan = nxt.valid ? ua_next : ua;
             }
             load_x(ksn);
             ld_scale(ksn, sc4, sh4);
@@ -290,6 +409,7 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
         // ---- epilogue: Y = A^T M A per (tile, channel); per lane 4 pixels x 4 quads of 4 consecutive channels ------------------------
         const int ch0 = 64 * cur_nt + 32 * wm + 4 * hh;                                  // + 8 g: first channel of quad g
         const int part = cur_mt * 4 + 2 * wn + ((lane >> 4) & 1);                        // this lane's 16-tile statistics group
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.slab, p.slab_bytes);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 o[4];
@@ -309,74 +429,52 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                     o[i * 2 + 1][e] = s[i][1] - s[i][2] - s[i][3];
                 }
             }
-            if constexpr (EPI == 0) {
+            if (seg.slot < 0) epi_quad<EPI, ODD>(p, ry, g, o, po, ch0, part, lane);
+            else {           // a piece of a remainder unit: the partial tile in register order (the output transform is linear)
+                const uint32_t so = (uint32_t)((wg * 2 + seg.slot) * 65536 + ((wave * 4 + g) * 4) * 1024 + lane * 16);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) bst4(ry, o[k], po[k] == OOB ? OOB : po[k] + 32u * g, 0);
-                if (p.pmean) {
-                    // (mean, M2) of the group's valid pixels per channel: sum -> mean -> sum of squared deviations, every reduction a
-                    // fixed-order DPP row sum. Slots outside the image (ODD) are zeroed and their (0 - mean)^2 taken back out.
-                    f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if constexpr (ODD) { if (po[k] == OOB) o[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                        s1 += o[k];
-                    }
-                    f32x4 mean, m2;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) mean[e] = row16_sum(s1[e]) * p.rcnt;
-                    f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const f32x4 dlt = o[k] - mean;
-                        s2 += dlt * dlt;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        m2[e] = row16_sum(s2[e]);
-                        if constexpr (ODD) m2[e] -= (64.f - p.cnt) * mean[e] * mean[e];
-                    }
-                    if ((lane & 15) == 0 && part < p.P) {
-                        *reinterpret_cast<f32x4*>(p.pmean + (size_t)part * p.Nc + ch0 + 8 * g) = mean;
-                        *reinterpret_cast<f32x4*>(p.pm2 + (size_t)part * p.Nc + ch0 + 8 * g) = m2;
-                    }
-                }
-            } else {
-                // in-block fused input gradient: g = gate . acc, gate = fma(y0, scale0, shift0) > 0 (the forward loader's own expression),
-                // sums of g and g * xhat0 per 64 pixels for the BatchNorm backward of the producer
-                const __amdgpu_buffer_rsrc_t r0y = make_rsrc(p.ey0, p.y_bytes);
-                f32x4 y0[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) y0[k] = bld4(r0y, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
-                const f32x4 esc = ld4(p.escale0 + ch0 + 8 * g), esh = ld4(p.eshift0 + ch0 + 8 * g);
-                const f32x4 emu = ld4(p.emean0 + ch0 + 8 * g), einv = ld4(p.einv0 + ch0 + 8 * g);
-                f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f32x4 gv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        bool on = __builtin_fmaf(y0[k][e], esc[e], esh[e]) > 0.f;
-                        if constexpr (ODD) on = on && po[k] != OOB;
-                        gv[e] = on ? o[k][e] : 0.f;
-                        sg[e] += gv[e];
-                        sgx[e] += gv[e] * ((y0[k][e] - emu[e]) * einv[e]);
-                    }
-                    bst4(ry, gv, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
-                }
-                if (p.esum) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { sg[e] = row16_sum(sg[e]); sgx[e] = row16_sum(sgx[e]); }
-                    if ((lane & 15) == 0 && part < p.P) {
-                        *reinterpret_cast<f32x4*>(p.esum + (size_t)part * p.Nc + ch0 + 8 * g) = sg;
-                        *reinterpret_cast<f32x4*>(p.esum + ((size_t)p.P + part) * p.Nc + ch0 + 8 * g) = sgx;
-                    }
-                }
+                for (int k = 0; k < 4; ++k) bst4(rs, o[k], so + (uint32_t)k * 1024u, 0);
             }
         }
-        if (!more) break;
+        if (!nxt.valid) break;
+        seg = nxt;
 #pragma unroll
         for (int k = 0; k < 4; ++k) po[k] = po_next[k];
         ua = ua_next;
+    }
+}
+
+// One workgroup per remainder unit: adds the unit's pieces (slab slots of the workgroups whose slice ranges meet it, in workgroup order)
+// and runs the ordinary epilogue with k_wino's own thread roles.
+template <int EPI, bool ODD>
+__global__ __launch_bounds__(256) void k_wino_fixup(WinoP p, int G) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int ntile = 32 * wn + (lane & 31), hh = lane >> 5;
+    const int u = blockIdx.x;                          // remainder unit
+    int mt, nt;
+    unit_of(p.q * G + u, p.MT, p.NT, mt, nt);
+    uint32_t po[4];
+    out_offsets(p, mt, nt, ntile, wm, hh, true, po);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.slab, p.slab_bytes);
+    const int s0 = u * p.KS, s1 = s0 + p.KS;
+    int w = (int)(((long)s0 * G) / ((long)p.r * p.KS));         // a workgroup at or before the first one that meets the unit
+    w = w > 0 ? w - 1 : 0;
+    while (piece_begin(w + 1, p.r, p.KS, G) <= s0) ++w;
+    const int ch0 = 64 * nt + 32 * wm + 4 * hh;
+    const int part = mt * 4 + 2 * wn + ((lane >> 4) & 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int ww = w; ww < G && piece_begin(ww, p.r, p.KS, G) < s1; ++ww) {
+            const int b0 = piece_begin(ww, p.r, p.KS, G), b1 = piece_begin(ww + 1, p.r, p.KS, G);
+            if (b1 <= b0) continue;
+            const int slot = (b0 / p.KS == u) ? 0 : 1;
+            const uint32_t so = (uint32_t)((ww * 2 + slot) * 65536 + ((wave * 4 + g) * 4) * 1024 + lane * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += bld4(rs, so + (uint32_t)k * 1024u, 0);
+        }
+        epi_quad<EPI, ODD>(p, ry, g, o, po, ch0, part, lane);
     }
 }
 
@@ -417,11 +515,21 @@ WinoP make_wp(const osi_conv_desc* d, const Geo& g, int Kc, int Nc) {
     return p;
 }
 
-int wino_grid(const WinoP& p) {
-    const int nb = ((p.MT + 7) / 8) * 8 * p.NT;
-    int cus = chip_cus() / 8 * 8;       // the persistent stride keeps blockIdx % 8 (the XCD) of a workgroup's units
-    if (cus < 8) cus = 8;
-    return nb < cus ? nb : cus;
+// persistent grid: one workgroup per CU the launch plans may use, a multiple of 8 (a workgroup's units keep its blockIdx % 8 = its XCD)
+int wino_grid() {
+    int cus = chip_cus() / 8 * 8;
+    return cus < 8 ? 8 : cus;
+}
+constexpr size_t SLOT_BYTES = 65536;      // one partial tile: 256 pixels x 64 channels, fp32
+size_t u_bytes_of(const osi_conv_desc* d) { return ((size_t)16 * d->Cin * d->Cout * sizeof(float) + 255) / 256 * 256; }
+size_t slab_bytes_of() { return (size_t)(hw_cus() / 8 * 8 < 8 ? 8 : hw_cus() / 8 * 8) * 2 * SLOT_BYTES; }
+
+// q full rounds + r remainder units over G workgroups; slab behind the transformed weights
+void plan_units(WinoP& p, void* ws, const osi_conv_desc* d, int G) {
+    const int V = p.MT * p.NT;
+    p.q = V / G; p.r = V - p.q * G;
+    p.slab = (float*)((char*)ws + u_bytes_of(d));
+    p.slab_bytes = (int)((size_t)G * 2 * SLOT_BYTES);
 }
 
 }  // namespace
@@ -438,10 +546,11 @@ int osi_conv_wino_eligible(const osi_conv_desc* d, int input_gradient) {
     return (input_gradient || g.uniform) ? 1 : 0;
 }
 
-/* bytes of the transformed-weight buffer (16 positions x Cin x Cout floats) both forms need; 0 = not eligible */
+/* bytes both forms need: the transformed weights (16 positions x Cin x Cout floats) + the slab of the stream-K remainder (two 64 KiB
+ * partial tiles per workgroup); 0 = not eligible */
 size_t osi_conv_wino_workspace(const osi_conv_desc* d) {
     if (!wino_shape(d)) return 0;
-    return (size_t)16 * d->Cin * d->Cout * sizeof(float);
+    return u_bytes_of(d) + slab_bytes_of();
 }
 
 /* Winograd twin of osi_conv_fwd_act / osi_conv_fwd_bnstats: in_scale / in_shift may be NULL (plain input). P = ceil(tiles / 16),
@@ -462,7 +571,9 @@ int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_sc
         *P = g.P; *rows_per_block = (int)g.cnt;
     }
     if (int e = launch_weights<0>(w, (float*)ws, d->Cin, d->Cout, st)) return e;
-    const dim3 grid((unsigned)wino_grid(p)), blk(256);
+    const int G = wino_grid();
+    plan_units(p, ws, d, G);
+    const dim3 grid((unsigned)G), blk(256);
     if (in_scale) {
         if (g.odd) hipLaunchKernelGGL((k_wino<true, 0, true>), grid, blk, 0, st, p);
         else hipLaunchKernelGGL((k_wino<true, 0, false>), grid, blk, 0, st, p);
@@ -471,6 +582,11 @@ int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_sc
         else hipLaunchKernelGGL((k_wino<false, 0, false>), grid, blk, 0, st, p);
     }
     OSI_LAUNCH_CHECK();
+    if (p.r > 0) {
+        if (g.odd) hipLaunchKernelGGL((k_wino_fixup<0, true>), dim3((unsigned)p.r), blk, 0, st, p, G);
+        else hipLaunchKernelGGL((k_wino_fixup<0, false>), dim3((unsigned)p.r), blk, 0, st, p, G);
+        OSI_LAUNCH_CHECK();
+    }
     return OSI_OK;
 }
 
@@ -496,10 +612,17 @@ int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const flo
     }
     *P = g.P;
     if (int e = launch_weights<1>(w, (float*)ws, d->Cout, d->Cin, st)) return e;
-    const dim3 grid((unsigned)wino_grid(p)), blk(256);
+    const int G = wino_grid();
+    plan_units(p, ws, d, G);
+    const dim3 grid((unsigned)G), blk(256);
     if (g.odd) hipLaunchKernelGGL((k_wino<false, 1, true>), grid, blk, 0, st, p);
     else hipLaunchKernelGGL((k_wino<false, 1, false>), grid, blk, 0, st, p);
     OSI_LAUNCH_CHECK();
+    if (p.r > 0) {
+        if (g.odd) hipLaunchKernelGGL((k_wino_fixup<1, true>), dim3((unsigned)p.r), blk, 0, st, p, G);
+        else hipLaunchKernelGGL((k_wino_fixup<1, false>), dim3((unsigned)p.r), blk, 0, st, p, G);
+        OSI_LAUNCH_CHECK();
+    }
     return OSI_OK;
 }
 

@@ -40,7 +40,7 @@ def _fwd(cuda, B, H, W, Cin, Cout, act, seed):
         a64 = torch.relu(a64 * _cpu64(sc) + _cpu64(sh))
     ref = F.conv2d(T.nchw(a64), T.oihw(_cpu64(w)), None, 1, 1).permute(0, 2, 3, 1).contiguous()
     wb = L.osi_conv_wino_workspace(ctypes.byref(d))
-    assert wb == 16 * Cin * Cout * 4
+    assert wb >= 16 * Cin * Cout * 4
     ws = torch.empty(wb, dtype=torch.uint8, device=cuda)
     tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
     Pn = (tiles + 15) // 16

@@ -26,6 +26,45 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+def cpu_quota():
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if a == "max" else round(int(a) / int(b), 2)
+    except (OSError, ValueError):
+        return None
+
+
+def photo_like(rng, w, h):
+    """An image with the entropy of a photograph, not of a smooth gradient: multi-octave noise (1/f-like spectrum: every octave upsampled
+    from a coarser grid), a few hard edges (rectangles / discs of flat colour) and sensor-like fine noise. At quality 90 a 500 x 375 image
+    of this kind is ~100-130 KB, ImageNet's typical size (round 2-4 used a 48 x 64 patch upscaled bicubically: ~25 KB, far cheaper to
+    entropy-decode)."""
+    from PIL import Image
+    acc = np.zeros((h, w, 3), dtype=np.float32)
+    amp, total = 1.0, 0.0
+    for octave in range(7):
+        gh, gw = max(2, h >> (6 - octave)), max(2, w >> (6 - octave))
+        grid = rng.random((gh, gw, 3), dtype=np.float32)
+        up = np.asarray(Image.fromarray((grid * 255).astype(np.uint8)).resize((w, h), Image.BICUBIC), dtype=np.float32) / 255.0
+        acc += amp * up
+        total += amp
+        amp *= 0.62
+    acc /= total
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(6):      # hard edges
+        colour = rng.random(3, dtype=np.float32)
+        if rng.random() < 0.5:
+            x0, y0 = int(rng.integers(0, w - 40)), int(rng.integers(0, h - 40))
+            x1, y1 = x0 + int(rng.integers(30, w // 2)), y0 + int(rng.integers(30, h // 2))
+            mask = (xx >= x0) & (xx < x1) & (yy >= y0) & (yy < y1)
+        else:
+            cx, cy, r = int(rng.integers(0, w)), int(rng.integers(0, h)), int(rng.integers(20, min(w, h) // 3))
+            mask = (xx - cx) ** 2 + (yy - cy) ** 2 < r * r
+        acc[mask] = 0.6 * acc[mask] + 0.4 * colour
+    acc += rng.normal(0.0, 0.012, size=acc.shape).astype(np.float32)
+    return (np.clip(acc, 0, 1) * 255).astype(np.uint8)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
@@ -39,12 +78,13 @@ def main():
     rng = np.random.default_rng(0)
     with tempfile.TemporaryDirectory() as d:
         rows = []
-        base = rng.integers(0, 256, size=(48, 64, 3), dtype=np.uint8)
         n_files = min(n, 1024)
+        sizes = []
         for i in range(n_files):
             w, h = int(rng.integers(400, 600)), int(rng.integers(300, 450))
-            img = Image.fromarray(base).resize((w, h), Image.BICUBIC)       # smooth content: realistic JPEG entropy
+            img = Image.fromarray(photo_like(rng, w, h))
             img.save(os.path.join(d, f"{i}.jpg"), quality=90)
+            sizes.append(os.path.getsize(os.path.join(d, f"{i}.jpg")))
         for i in range(n):
             rows.append(f"{i % n_files}.jpg,{-1 if i % 3 == 0 else i % C}")
         csv = os.path.join(d, "p2_train.csv")
@@ -81,15 +121,41 @@ def main():
             torch.cuda.synchronize()
             return it_n * B / (time.perf_counter() - t0)
 
-        out = {"images": n, "batch": B, "workers": workers, "host_cpus": os.cpu_count()}
+        out = {"images": n, "batch": B, "workers": workers, "host_cpus": os.cpu_count(), "cgroup_cpu_quota": cpu_quota()}
+        out["jpeg_bytes_mean"] = int(np.mean(sizes))
+        # one core's cost per image, split: decode vs Resize(256) (what the host still does)
+        t_dec = t_res = 0.0
+        for i in range(64):
+            t0 = time.perf_counter()
+            im = Image.open(os.path.join(d, f"{i}.jpg")).convert("RGB")
+            t1 = time.perf_counter()
+            im = im.resize(P.resize_size(*im.size), Image.BILINEAR)
+            t2 = time.perf_counter()
+            t_dec += t1 - t0; t_res += t2 - t1
+        out["host_ms_per_image_one_core"] = {"jpeg_decode": round(t_dec / 64 * 1e3, 3), "resize256": round(t_res / 64 * 1e3, 3)}
+
+        class Resident:     # the synthetic headline inside the SAME loop: one device-resident batch yielded len(loader) times
+            def __init__(self, n_batches):
+                self.n = n_batches
+                g = torch.Generator(device="cuda").manual_seed(1)
+                self.x = torch.rand(B, 3, 224, 224, device="cuda", generator=g)
+                self.y = torch.randint(-1, C, (B,), device="cuda", generator=g)
+            def __len__(self): return self.n
+            def __iter__(self):
+                for _ in range(self.n):
+                    yield self.x, self.y
+
         ref, canv = loader(False), loader(True)
         epoch(canv)                                  # warm-up: worker start-up, kernels, allocator
         out["jpeg_files"] = n_files
+        out["train_synthetic_resident_img_s"] = round(epoch(Resident(len(canv))), 1)
         out["loader_only_reference_fp32_img_s"] = round(epoch(ref, False), 1)
         out["loader_only_canvas_u8_img_s"] = round(epoch(canv, False), 1)
         out["train_reference_style_img_s"] = round(epoch(ref), 1)
         out["train_canvas_img_s"] = round(epoch(Staged(canv)), 1)
         out["train_canvas_prefetch_img_s"] = round(epoch(P.DevicePrefetcher(canv)), 1)
+        out["train_synthetic_resident_img_s_after"] = round(epoch(Resident(len(canv))), 1)
+        out["end_to_end_vs_synthetic"] = round(out["train_canvas_prefetch_img_s"] / out["train_synthetic_resident_img_s"], 4)
         print(json.dumps(out))
 
 
