@@ -57,7 +57,7 @@ struct WinoP {
     const float *escale0, *eshift0, *emean0, *einv0;
     float* esum;         // [3][P][Nc]: sum g, sum g * xhat0 (third plane unused)
     // work decomposition: q full rounds of whole units, r remainder units cut along K into G pieces (slab: 2 slots of 64 KiB per workgroup)
-    int q, r;
+    int q, r, nfull;
     float* slab;
     int slab_bytes;
 };
@@ -156,13 +156,14 @@ __device__ __forceinline__ Seg seg_phase2(int w, int q, int r, int KS, int G, bo
     if (b1 > (u0 + 1) * KS) { s.v = q * G + u0 + 1; s.ks0 = 0; s.ks1 = b1 - (u0 + 1) * KS; s.slot = 1; s.valid = true; }
     return s;
 }
-__device__ __forceinline__ Seg seg_first(int w, int q, int r, int KS, int G) {
-    if (q > 0) return Seg{w, 0, KS, -1, true};
+// nfull = units that run whole (q G; or all V of them when the remainder is not cut: knob wino_streamk = 0, then r = 0)
+__device__ __forceinline__ Seg seg_first(int w, int nfull, int q, int r, int KS, int G) {
+    if (w < nfull) return Seg{w, 0, KS, -1, true};
     return seg_phase2(w, q, r, KS, G, false, 0);
 }
-__device__ __forceinline__ Seg seg_next(const Seg& c, int w, int q, int r, int KS, int G) {
+__device__ __forceinline__ Seg seg_next(const Seg& c, int w, int nfull, int q, int r, int KS, int G) {
     if (c.slot < 0) {                                   // phase 1
-        if (c.v + G < q * G) return Seg{c.v + G, 0, KS, -1, true};
+        if (c.v + G < nfull) return Seg{c.v + G, 0, KS, -1, true};
         return seg_phase2(w, q, r, KS, G, false, 0);
     }
     if (c.slot == 0) return seg_phase2(w, q, r, KS, G, true, 0);
@@ -170,11 +171,11 @@ __device__ __forceinline__ Seg seg_next(const Seg& c, int w, int q, int r, int K
 }
 
 // ---- epilogue of one channel quad (4 pixels x 4 consecutive channels of this lane's tile), shared by k_wino and k_wino_fixup -------------
-// EPI 0 forward: y + optional (mean, M2) statistics per 16 tiles; EPI 1: the in-block fused input gradient (gate, dx, sums).
-template <int EPI, bool ODD>
-__device__ __forceinline__ void epi_quad(const WinoP& p, __amdgpu_buffer_rsrc_t ry, int g, f32x4 (&o)[4], const uint32_t (&po)[4], int ch0,
-                                         int part, int lane) {
-    if constexpr (EPI == 0) {
+// Forward: y + optional (mean, M2) statistics per 16 tiles.
+template <bool ODD>
+__device__ __forceinline__ void epi0_quad(const WinoP& p, __amdgpu_buffer_rsrc_t ry, int g, f32x4 (&o)[4], const uint32_t (&po)[4], int ch0,
+                                          int part, int lane) {
+    {
 #pragma unroll
         for (int k = 0; k < 4; ++k) bst4(ry, o[k], po[k] == OOB ? OOB : po[k] + 32u * g, 0);
         if (p.pmean) {
@@ -205,35 +206,44 @@ __device__ __forceinline__ void epi_quad(const WinoP& p, __amdgpu_buffer_rsrc_t 
                 *reinterpret_cast<f32x4*>(p.pm2 + (size_t)part * p.Nc + ch0 + 8 * g) = m2;
             }
         }
-    } else {
-        // g = gate . acc, gate = fma(y0, scale0, shift0) > 0 (the forward loader's own expression); sums of g and g * xhat0 per 64 pixels
-        const __amdgpu_buffer_rsrc_t r0y = make_rsrc(p.ey0, p.y_bytes);
-        f32x4 y0[4];
+    }
+}
+
+// Operands of the input-gradient epilogue of one channel quad: the producer's pre-BN values at this lane's four pixels and the per-channel
+// gate / xhat coefficients. Loaded one quad AHEAD of their use (k_wino) — a lone wave per SIMD has nothing else to cover the round trip.
+struct Epi1Ops { f32x4 y0[4], esc, esh, emu, einv; };
+__device__ __forceinline__ Epi1Ops epi1_load(const WinoP& p, __amdgpu_buffer_rsrc_t r0y, int g, const uint32_t (&po)[4], int ch0) {
+    Epi1Ops L;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) y0[k] = bld4(r0y, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
-        const f32x4 esc = ld4(p.escale0 + ch0 + 8 * g), esh = ld4(p.eshift0 + ch0 + 8 * g);
-        const f32x4 emu = ld4(p.emean0 + ch0 + 8 * g), einv = ld4(p.einv0 + ch0 + 8 * g);
-        f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 4; ++k) L.y0[k] = bld4(r0y, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+    L.esc = ld4(p.escale0 + ch0 + 8 * g); L.esh = ld4(p.eshift0 + ch0 + 8 * g);
+    L.emu = ld4(p.emean0 + ch0 + 8 * g); L.einv = ld4(p.einv0 + ch0 + 8 * g);
+    return L;
+}
+// g = gate . acc, gate = fma(y0, scale0, shift0) > 0 (the forward loader's own expression); sums of g and g * xhat0 per 64 pixels
+template <bool ODD>
+__device__ __forceinline__ void epi1_apply(const WinoP& p, __amdgpu_buffer_rsrc_t ry, int g, const f32x4 (&o)[4], const uint32_t (&po)[4],
+                                           int ch0, int part, int lane, const Epi1Ops& L) {
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            f32x4 gv;
+    for (int k = 0; k < 4; ++k) {
+        f32x4 gv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bool on = __builtin_fmaf(y0[k][e], esc[e], esh[e]) > 0.f;
-                if constexpr (ODD) on = on && po[k] != OOB;
-                gv[e] = on ? o[k][e] : 0.f;
-                sg[e] += gv[e];
-                sgx[e] += gv[e] * ((y0[k][e] - emu[e]) * einv[e]);
-            }
-            bst4(ry, gv, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+        for (int e = 0; e < 4; ++e) {
+            bool on = __builtin_fmaf(L.y0[k][e], L.esc[e], L.esh[e]) > 0.f;
+            if constexpr (ODD) on = on && po[k] != OOB;
+            gv[e] = on ? o[k][e] : 0.f;
+            sg[e] += gv[e];
+            sgx[e] += gv[e] * ((L.y0[k][e] - L.emu[e]) * L.einv[e]);
         }
-        if (p.esum) {
+        bst4(ry, gv, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+    }
+    if (p.esum) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { sg[e] = row16_sum(sg[e]); sgx[e] = row16_sum(sgx[e]); }
-            if ((lane & 15) == 0 && part < p.P) {
-                *reinterpret_cast<f32x4*>(p.esum + (size_t)part * p.Nc + ch0 + 8 * g) = sg;
-                *reinterpret_cast<f32x4*>(p.esum + ((size_t)p.P + part) * p.Nc + ch0 + 8 * g) = sgx;
-            }
+        for (int e = 0; e < 4; ++e) { sg[e] = row16_sum(sg[e]); sgx[e] = row16_sum(sgx[e]); }
+        if ((lane & 15) == 0 && part < p.P) {
+            *reinterpret_cast<f32x4*>(p.esum + (size_t)part * p.Nc + ch0 + 8 * g) = sg;
+            *reinterpret_cast<f32x4*>(p.esum + ((size_t)p.P + part) * p.Nc + ch0 + 8 * g) = sgx;
         }
     }
 }
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
     const int ntile = 32 * wn + (lane & 31), hh = lane >> 5;
     const int THW = p.TH * p.TW;
 
-    Seg seg = seg_first(wg, p.q, p.r, p.KS, G);
+    Seg seg = seg_first(wg, p.nfull, p.q, p.r, p.KS, G);
     if (!seg.valid) return;
     int mt, nt;
     unit_of(seg.v, p.MT, p.NT, mt, nt);
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
             int ksn = ks + 1;
             uint32_t uan = ua;
             if (last) {      // uniform: the next segment of this workgroup (or a dead one: every offset out of range) — no loads in here
-                nxt = seg_next(seg, wg, p.q, p.r, p.KS, G);
+                nxt = seg_next(seg, wg, p.nfull, p.q, p.r, p.KS, G);
                 if (nxt.valid) unit_of(nxt.v, p.MT, p.NT, mt, nt);
                 setup(mt, nt, nxt.valid, po_next, ua_next);
                 ksn = nxt.valid ? nxt.ks0 : 0;
@@ -410,6 +420,9 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
         const int ch0 = 64 * cur_nt + 32 * wm + 4 * hh;                                  // + 8 g: first channel of quad g
         const int part = cur_mt * 4 + 2 * wn + ((lane >> 4) & 1);                        // this lane's 16-tile statistics group
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.slab, p.slab_bytes);
+        const __amdgpu_buffer_rsrc_t r0y = make_rsrc(EPI == 1 ? p.ey0 : p.y, p.y_bytes);
+        Epi1Ops L1{};
+        if constexpr (EPI == 1) { if (seg.slot < 0) L1 = epi1_load(p, r0y, 0, po, ch0); }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 o[4];
@@ -429,8 +442,14 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                     o[i * 2 + 1][e] = s[i][1] - s[i][2] - s[i][3];
                 }
             }
-            if (seg.slot < 0) epi_quad<EPI, ODD>(p, ry, g, o, po, ch0, part, lane);
-            else {           // a piece of a remainder unit: the partial tile in register order (the output transform is linear)
+            if (seg.slot < 0) {
+                if constexpr (EPI == 0) epi0_quad<ODD>(p, ry, g, o, po, ch0, part, lane);
+                else {
+                    const Epi1Ops Ln = epi1_load(p, r0y, g < 3 ? g + 1 : 3, po, ch0);      // the next quad's operands behind this quad's arithmetic
+                    epi1_apply<ODD>(p, ry, g, o, po, ch0, part, lane, L1);
+                    L1 = Ln;
+                }
+            } else {           // a piece of a remainder unit: the partial tile in register order (the output transform is linear)
                 const uint32_t so = (uint32_t)((wg * 2 + seg.slot) * 65536 + ((wave * 4 + g) * 4) * 1024 + lane * 16);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) bst4(rs, o[k], so + (uint32_t)k * 1024u, 0);
@@ -444,13 +463,14 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
     }
 }
 
-// One workgroup per remainder unit: adds the unit's pieces (slab slots of the workgroups whose slice ranges meet it, in workgroup order)
-// and runs the ordinary epilogue with k_wino's own thread roles.
+// One WAVE per (remainder unit, wave role, channel quad) — 16 single-wave workgroups per unit, so that a small remainder still fills the
+// chip: adds the unit's pieces (slab slots of the workgroups whose slice ranges meet it, in workgroup order) and runs the ordinary
+// epilogue of that quad with k_wino's own lane roles (the statistics / sums are per DPP row of 16 lanes: a wave is self-contained).
 template <int EPI, bool ODD>
-__global__ __launch_bounds__(256) void k_wino_fixup(WinoP p, int G) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+__global__ __launch_bounds__(64) void k_wino_fixup(WinoP p, int G) {
+    const int lane = threadIdx.x, u = blockIdx.x >> 4, wave = (blockIdx.x >> 2) & 3, g = blockIdx.x & 3;
+    const int wm = wave >> 1, wn = wave & 1;
     const int ntile = 32 * wn + (lane & 31), hh = lane >> 5;
-    const int u = blockIdx.x;                          // remainder unit
     int mt, nt;
     unit_of(p.q * G + u, p.MT, p.NT, mt, nt);
     uint32_t po[4];
@@ -461,20 +481,23 @@ __global__ __launch_bounds__(256) void k_wino_fixup(WinoP p, int G) {
     int w = (int)(((long)s0 * G) / ((long)p.r * p.KS));         // a workgroup at or before the first one that meets the unit
     w = w > 0 ? w - 1 : 0;
     while (piece_begin(w + 1, p.r, p.KS, G) <= s0) ++w;
-    const int ch0 = 64 * nt + 32 * wm + 4 * hh;
-    const int part = mt * 4 + 2 * wn + ((lane >> 4) & 1);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        for (int ww = w; ww < G && piece_begin(ww, p.r, p.KS, G) < s1; ++ww) {
-            const int b0 = piece_begin(ww, p.r, p.KS, G), b1 = piece_begin(ww + 1, p.r, p.KS, G);
-            if (b1 <= b0) continue;
+    f32x4 o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int b0 = piece_begin(w, p.r, p.KS, G);
+    for (int ww = w; ww < G && b0 < s1; ++ww) {
+        const int b1 = piece_begin(ww + 1, p.r, p.KS, G);
+        if (b1 > b0) {
             const int slot = (b0 / p.KS == u) ? 0 : 1;
             const uint32_t so = (uint32_t)((ww * 2 + slot) * 65536 + ((wave * 4 + g) * 4) * 1024 + lane * 16);
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] += bld4(rs, so + (uint32_t)k * 1024u, 0);
         }
-        epi_quad<EPI, ODD>(p, ry, g, o, po, ch0, part, lane);
+        b0 = b1;
+    }
+    const int ch0 = 64 * nt + 32 * wm + 4 * hh, part = mt * 4 + 2 * wn + ((lane >> 4) & 1);
+    if constexpr (EPI == 0) epi0_quad<ODD>(p, ry, g, o, po, ch0, part, lane);
+    else {
+        const Epi1Ops L = epi1_load(p, make_rsrc(p.ey0, p.y_bytes), g, po, ch0);
+        epi1_apply<ODD>(p, ry, g, o, po, ch0, part, lane, L);
     }
 }
 
@@ -527,7 +550,10 @@ size_t slab_bytes_of() { return (size_t)(hw_cus() / 8 * 8 < 8 ? 8 : hw_cus() / 8
 // q full rounds + r remainder units over G workgroups; slab behind the transformed weights
 void plan_units(WinoP& p, void* ws, const osi_conv_desc* d, int G) {
     const int V = p.MT * p.NT;
-    p.q = V / G; p.r = V - p.q * G;
+    p.q = V / G; p.r = V - p.q * G; p.nfull = p.q * G;
+    // short units (KS <= 4: the 64-channel layers) keep their ragged last round: a piece of one or two slices plus the fix-up pass costs
+    // what the balance returns (measured: 205 vs 205 us forward, 232 vs 228 us input gradient at 56 x 56)
+    if (!g_osi_tuning.wino_streamk || p.KS <= 4) { p.nfull = V; p.r = 0; }
     p.slab = (float*)((char*)ws + u_bytes_of(d));
     p.slab_bytes = (int)((size_t)G * 2 * SLOT_BYTES);
 }
@@ -583,8 +609,8 @@ int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_sc
     }
     OSI_LAUNCH_CHECK();
     if (p.r > 0) {
-        if (g.odd) hipLaunchKernelGGL((k_wino_fixup<0, true>), dim3((unsigned)p.r), blk, 0, st, p, G);
-        else hipLaunchKernelGGL((k_wino_fixup<0, false>), dim3((unsigned)p.r), blk, 0, st, p, G);
+        if (g.odd) hipLaunchKernelGGL((k_wino_fixup<0, true>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
+        else hipLaunchKernelGGL((k_wino_fixup<0, false>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
         OSI_LAUNCH_CHECK();
     }
     return OSI_OK;
@@ -619,8 +645,8 @@ int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const flo
     else hipLaunchKernelGGL((k_wino<false, 1, false>), grid, blk, 0, st, p);
     OSI_LAUNCH_CHECK();
     if (p.r > 0) {
-        if (g.odd) hipLaunchKernelGGL((k_wino_fixup<1, true>), dim3((unsigned)p.r), blk, 0, st, p, G);
-        else hipLaunchKernelGGL((k_wino_fixup<1, false>), dim3((unsigned)p.r), blk, 0, st, p, G);
+        if (g.odd) hipLaunchKernelGGL((k_wino_fixup<1, true>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
+        else hipLaunchKernelGGL((k_wino_fixup<1, false>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
         OSI_LAUNCH_CHECK();
     }
     return OSI_OK;

@@ -72,7 +72,8 @@ def test_forward_network_shapes_at_the_benchmarked_batch(cuda, C, H):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,act", [(6, 7, 7, 64, 128, True),      # 96 tiles: the second unit is half empty; tiles hang over the border
                                                 (4, 7, 7, 32, 64, False),      # Cin = 32: two K slices; plain input
                                                 (8, 12, 20, 48, 64, True),     # non-square, Cin % 16 == 0 only
-                                                (16, 14, 14, 64, 192, True)])  # 784 tiles = 12.25 units, three column units
+                                                (16, 14, 14, 64, 192, True),   # 784 tiles = 12.25 units, three column units
+                                                (16, 14, 14, 128, 64, True)])  # 13 units of 8 K slices on 256 CUs: every unit cut into 8 stream-K pieces
 def test_forward_ragged_and_odd_geometries(cuda, B, H, W, Cin, Cout, act):
     _fwd(cuda, B, H, W, Cin, Cout, act, 1)
 
@@ -130,7 +131,8 @@ def test_input_gradient_network_shapes_at_the_benchmarked_batch(cuda, C, H):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 14, 14, 64, 64),      # 147 tiles: the last statistics group and the last unit are ragged
                                             (6, 7, 7, 128, 64),       # tiles over the border; more input- than output-gradient channels
-                                            (5, 10, 6, 64, 48)])      # non-square; Cout % 16 == 0 only
+                                            (5, 10, 6, 64, 48),       # non-square; Cout % 16 == 0 only
+                                            (5, 14, 14, 64, 160)])    # 10 K slices per unit, 4 units: stream-K pieces + fix-up with the fused epilogue
 def test_input_gradient_ragged_and_odd_geometries(cuda, B, H, W, Cin, Cout):
     a = _dgrad(cuda, B, H, W, Cin, Cout, 2)
     b = _dgrad(cuda, B, H, W, Cin, Cout, 2, partials=False)
