@@ -106,6 +106,20 @@ class CanvasDataset(torch.utils.data.Dataset):
         return torch.from_numpy(np.array(x)).permute(2, 0, 1).float().div_(255.0), label   # ToTensor() on the host
 
 
+def worker_init(worker_id=0, niceness=10):
+    """DataLoader `worker_init_fn`: the decode workers run at a lower scheduling priority than the process that launches the GPU work.
+    On a lease of N CPUs per GPU the workers (N of them, bursty: they run ahead until the prefetch queues are full) otherwise compete
+    with the one thread whose latency the GPU sees — kernel launches queue up behind decode time slices and the step shows bubbles
+    (profiles/r05_input_pipeline.json: 0.91 -> see there of the synthetic rate at 16 workers on 16 CPUs). Also keeps every worker to one
+    intra-op thread."""
+    import os
+    try:
+        os.nice(niceness)
+    except OSError:
+        pass
+    torch.set_num_threads(1)
+
+
 def stage_canvas_batch(canvas, crop_xy, flip, out=None, crop=CROP, stream=None):
     """uint8 canvases [B,Hc,Wc,3] + crop corners int32 [B,2] + flip flags uint8 [B] (all on the GPU) -> fp32 [B,crop,crop,4]
     (NHWC4, the executor's input layout) in one kernel on `stream` (default: the current stream)."""

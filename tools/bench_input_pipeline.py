@@ -37,7 +37,7 @@ def cpu_quota():
 def photo_like(rng, w, h):
     """An image with the entropy of a photograph, not of a smooth gradient: multi-octave noise (1/f-like spectrum: every octave upsampled
     from a coarser grid), a few hard edges (rectangles / discs of flat colour) and sensor-like fine noise. At quality 90 a 500 x 375 image
-    of this kind is ~100-130 KB, ImageNet's typical size (round 2-4 used a 48 x 64 patch upscaled bicubically: ~25 KB, far cheaper to
+    of this kind is ~105-115 KB, ImageNet's typical size (round 2-4 used a 48 x 64 patch upscaled bicubically: ~25 KB, far cheaper to
     entropy-decode)."""
     from PIL import Image
     acc = np.zeros((h, w, 3), dtype=np.float32)
@@ -48,7 +48,7 @@ def photo_like(rng, w, h):
         up = np.asarray(Image.fromarray((grid * 255).astype(np.uint8)).resize((w, h), Image.BICUBIC), dtype=np.float32) / 255.0
         acc += amp * up
         total += amp
-        amp *= 0.62
+        amp *= 1.1
     acc /= total
     yy, xx = np.mgrid[0:h, 0:w]
     for _ in range(6):      # hard edges
@@ -61,14 +61,26 @@ def photo_like(rng, w, h):
             cx, cy, r = int(rng.integers(0, w)), int(rng.integers(0, h)), int(rng.integers(20, min(w, h) // 3))
             mask = (xx - cx) ** 2 + (yy - cy) ** 2 < r * r
         acc[mask] = 0.6 * acc[mask] + 0.4 * colour
-    acc += rng.normal(0.0, 0.012, size=acc.shape).astype(np.float32)
+    acc += rng.normal(0.0, 0.07, size=acc.shape).astype(np.float32)
     return (np.clip(acc, 0, 1) * 255).astype(np.uint8)
+
+
+def write_jpeg(arg):
+    from PIL import Image
+    d, i = arg
+    rng = np.random.default_rng(1000 + i)
+    w, h = int(rng.integers(400, 600)), int(rng.integers(300, 450))
+    path = os.path.join(d, f"{i}.jpg")
+    Image.fromarray(photo_like(rng, w, h)).save(path, quality=90)
+    return os.path.getsize(path)
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else min(16, os.cpu_count() or 4)
+    nice = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] != "-" else None          # niceness of the decode workers (pipeline.worker_init); default: none
+    quick = len(sys.argv) > 5 and sys.argv[5] == "quick"            # only synthetic / loader-only / canvas + prefetch
     from PIL import Image
     from openset_imagenet import ResNet50, EntropicOpensetLoss, AverageMeter, optim, tools, pipeline as P
     from openset_imagenet.train import train
@@ -79,21 +91,21 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         rows = []
         n_files = min(n, 1024)
-        sizes = []
-        for i in range(n_files):
-            w, h = int(rng.integers(400, 600)), int(rng.integers(300, 450))
-            img = Image.fromarray(photo_like(rng, w, h))
-            img.save(os.path.join(d, f"{i}.jpg"), quality=90)
-            sizes.append(os.path.getsize(os.path.join(d, f"{i}.jpg")))
+        import multiprocessing as mp
+        with mp.Pool(min(16, os.cpu_count() or 1)) as pool:       # ~0.4 s per image on one core
+            sizes = pool.map(write_jpeg, [(d, i) for i in range(n_files)])
         for i in range(n):
             rows.append(f"{i % n_files}.jpg,{-1 if i % 3 == 0 else i % C}")
         csv = os.path.join(d, "p2_train.csv")
         open(csv, "w").write("\n".join(rows) + "\n")
 
-        def loader(uint8):
+        def loader(uint8, nw=None, nice=nice):
+            nw = workers if nw is None else nw
             ds = P.CanvasDataset(csv, d, True, "entropic", uint8)
-            return torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True, num_workers=workers, pin_memory=True, drop_last=True,
-                                               persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
+            import functools
+            return torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True, num_workers=nw, pin_memory=True, drop_last=True,
+                                               persistent_workers=nw > 0, prefetch_factor=4 if nw > 0 else None,
+                                               worker_init_fn=None if nice is None else functools.partial(P.worker_init, niceness=nice))
 
         class Staged:      # canvas batches staged inside the step (no copy stream): isolates what the prefetch adds
             def __init__(self, ld): self.ld = ld
@@ -121,7 +133,7 @@ def main():
             torch.cuda.synchronize()
             return it_n * B / (time.perf_counter() - t0)
 
-        out = {"images": n, "batch": B, "workers": workers, "host_cpus": os.cpu_count(), "cgroup_cpu_quota": cpu_quota()}
+        out = {"images": n, "batch": B, "workers": workers, "worker_niceness": nice, "host_cpus": os.cpu_count(), "cgroup_cpu_quota": cpu_quota()}
         out["jpeg_bytes_mean"] = int(np.mean(sizes))
         # one core's cost per image, split: decode vs Resize(256) (what the host still does)
         t_dec = t_res = 0.0
@@ -145,14 +157,22 @@ def main():
                 for _ in range(self.n):
                     yield self.x, self.y
 
-        ref, canv = loader(False), loader(True)
+        def note(msg):
+            print(f"[bench_input_pipeline] {msg}", file=sys.stderr, flush=True)
+        note(f"{n_files} JPEG files written, mean {out['jpeg_bytes_mean']} bytes")
+        ref, canv = (None if quick else loader(False)), loader(True)
         epoch(canv)                                  # warm-up: worker start-up, kernels, allocator
         out["jpeg_files"] = n_files
         out["train_synthetic_resident_img_s"] = round(epoch(Resident(len(canv))), 1)
-        out["loader_only_reference_fp32_img_s"] = round(epoch(ref, False), 1)
+        note("synthetic done")
+        if not quick:
+            out["loader_only_reference_fp32_img_s"] = round(epoch(ref, False), 1)
         out["loader_only_canvas_u8_img_s"] = round(epoch(canv, False), 1)
-        out["train_reference_style_img_s"] = round(epoch(ref), 1)
-        out["train_canvas_img_s"] = round(epoch(Staged(canv)), 1)
+        note("loader-only done")
+        if not quick:
+            out["train_reference_style_img_s"] = round(epoch(ref), 1)
+            out["train_canvas_img_s"] = round(epoch(Staged(canv)), 1)
+            note("reference-style / staged done")
         out["train_canvas_prefetch_img_s"] = round(epoch(P.DevicePrefetcher(canv)), 1)
         out["train_synthetic_resident_img_s_after"] = round(epoch(Resident(len(canv))), 1)
         out["end_to_end_vs_synthetic"] = round(out["train_canvas_prefetch_img_s"] / out["train_synthetic_resident_img_s"], 4)
