@@ -24,6 +24,7 @@
 // The K order inside a stage is permuted identically for both operands (lane half h of MFMA (j,e) consumes
 // k = 8j + 4h + e), which a dot product does not care about.
 #include "conv_common.h"
+#include <algorithm>
 
 using namespace osi_conv;
 
@@ -1869,6 +1870,19 @@ static TailPlan plan_tail_split(long MT, int NT, int T) {
     long S = ncu / rem;
     if (S > T / g_osi_tuning.tail_mint) S = T / g_osi_tuning.tail_mint;
     if (S > g_osi_tuning.tail_smax) S = g_osi_tuning.tail_smax;
+    if (q <= 2) {
+        // Few rounds (small batches: B = 64 halves every M of the B = 128 plans; the 7x7 layers run 1.5 rounds, the 14x14 ones 3): the
+        // remainder may be larger than half the chip, where one round of floor(N / rem) pieces per tile is no split at all. Pieces may
+        // then take several rounds of their own: S pieces per tile cost ceil(rem S / N) / S of a tile time instead of 1 — pick the S
+        // with the least modelled time (392 tiles on 256 CUs: S = 3 -> 1 + 2/3 instead of 2 rounds).
+        const long smax = std::min<long>(g_osi_tuning.tail_smax, T / g_osi_tuning.tail_mint);
+        double best = S >= 2 ? 1.0 / (double)S : 1.0;
+        for (long c = 2; c <= smax; ++c) {
+            const double cost = (double)((rem * c + ncu - 1) / ncu) / (double)c;
+            if (cost < best - 1e-9) { best = cost; S = c; }
+        }
+        if ((1.0 - best) / (double)(q + 1) * 100.0 < (double)g_osi_tuning.tail_gain) return t;
+    }
     if (S <= 1) return t;
     const int ksT = (int)((T + S - 1) / S);
     S = (T + ksT - 1) / ksT;

@@ -553,7 +553,9 @@ void plan_units(WinoP& p, void* ws, const osi_conv_desc* d, int G) {
     p.q = V / G; p.r = V - p.q * G; p.nfull = p.q * G;
     // short units (KS <= 4: the 64-channel layers) keep their ragged last round: a piece of one or two slices plus the fix-up pass costs
     // what the balance returns (measured: 205 vs 205 us forward, 232 vs 228 us input gradient at 56 x 56)
-    if (!g_osi_tuning.wino_streamk || p.KS <= 4) { p.nfull = V; p.r = 0; }
+    // — unless the ragged round is a large part of a short launch (small batches: B = 64 leaves 16 units for a 4th round of 3.06)
+    const bool heavy_tail = p.r > 0 && (double)(G - p.r) / (double)G / (double)(p.q + 1) >= 0.15;
+    if (!g_osi_tuning.wino_streamk || (p.KS <= 4 && !heavy_tail)) { p.nfull = V; p.r = 0; }
     p.slab = (float*)((char*)ws + u_bytes_of(d));
     p.slab_bytes = (int)((size_t)G * 2 * SLOT_BYTES);
 }

@@ -1,5 +1,5 @@
 """Oracle parity on the PRODUCTION launch plans: every convolution shape of ResNet-50 at 224 x 224 at the
-benchmarked batch (B = 128; the layer3 / layer4 shapes also at B = 256, Protocol 3), called through the C ABI in exactly the
+benchmarked batch (B = 128; every shape also at the reference's default B = 64; the layer3 / layer4 shapes also at B = 256, Protocol 3), called through the C ABI in exactly the
 FORMS the executor issues (csrc/resnet50_exec.hip) with AUTO tiles and default tuning — i.e. with the tile rule, the K-split tails
 on a 256-CU plan, the 2048-workgroup split-K budget, the XCD slot mapping and byte offsets of the real step — against torch-CPU
 fp64 (`F.conv2d`, `conv2d_input`, `conv2d_weight`: the arithmetic the reference runs under openset_imagenet/model.py:37 and, for
@@ -63,6 +63,9 @@ def _cases(table):
     out = []
     for key, stage in table.items():
         out.append(pytest.param(key, 128, id="-".join(str(int(v) if isinstance(v, bool) else v) for v in key) + "-b128"))
+        # the reference's own default batch (config/train.yaml:18): half of every M — other tail plans (pieces over several rounds where the
+        # launch has at most two full rounds), other split-K budgets
+        out.append(pytest.param(key, 64, id="-".join(str(int(v) if isinstance(v, bool) else v) for v in key) + "-b64"))
         if stage >= 2:
             out.append(pytest.param(key, 256, id="-".join(str(int(v) if isinstance(v, bool) else v) for v in key) + "-b256"))
     return out
