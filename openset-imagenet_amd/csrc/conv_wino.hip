@@ -83,17 +83,22 @@ __device__ __forceinline__ float row16_sum(float v) {
 // g[r][s] = w[k][2 - r][2 - s][n] (taps rotated by 180 degrees).
 template <int FLIP>
 __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ w, float* __restrict__ u, int Kc, int Nc, int KS, int CB) {
+    // one thread per (4 consecutive k = one 16-byte fragment element group, n): 16 stores of 16 B, consecutive n = consecutive lanes = 512 B runs
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= Kc * Nc) return;
-    // the fastest thread index walks the contiguous axis of w: cin = k (forward) or cin = n (input gradient)
-    const int k = FLIP ? idx / Nc : idx % Kc, n = FLIP ? idx % Nc : idx / Kc;
-    float g[3][3];
+    const int K4 = Kc / 4;
+    if (idx >= K4 * Nc) return;
+    const int n = idx % Nc, k0 = (idx / Nc) * 4;
+    f32x4 g[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-            g[r][s] = FLIP ? w[((size_t)(k * 3 + (2 - r)) * 3 + (2 - s)) * Nc + n] : w[((size_t)(n * 3 + r) * 3 + s) * Kc + k];
-    float t[4][3];
+        for (int s = 0; s < 3; ++s) {
+            if (FLIP) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[r][s][e] = w[((size_t)((k0 + e) * 3 + (2 - r)) * 3 + (2 - s)) * Nc + n];
+            } else g[r][s] = ld4(w + ((size_t)(n * 3 + r) * 3 + s) * Kc + k0);
+        }
+    f32x4 t[4][3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         t[0][s] = g[0][s];
@@ -101,10 +106,10 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
         t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
         t[3][s] = g[2][s];
     }
-    const int ks = k / KC, j = (k % KC) / 8, h = (k % 8) / 4, e = k % 4, cb = n / 32, lane = h * 32 + n % 32;
+    const int ks = k0 / KC, j = (k0 % KC) / 8, h = (k0 % 8) / 4, cb = n / 32, lane = h * 32 + n % 32;
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi) {
-        float v[4];
+        f32x4 v[4];
         v[0] = t[xi][0];
         v[1] = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]);
         v[2] = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]);
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
             const int p = xi * 4 + nu;
-            u[((((size_t)(p * KS + ks) * CB + cb) * 2 + j) * 64 + lane) * 4 + e] = v[nu];
+            *reinterpret_cast<f32x4*>(u + ((((size_t)(p * KS + ks) * CB + cb) * 2 + j) * 64 + lane) * 4) = v[nu];
         }
     }
 }
@@ -523,7 +528,7 @@ Geo geo_of(const osi_conv_desc* d) {
 
 template <int FLIP>
 int launch_weights(const float* w, float* u, int Kc, int Nc, hipStream_t st) {
-    hipLaunchKernelGGL(k_wino_weights<FLIP>, dim3((unsigned)((Kc * Nc + 255) / 256)), dim3(256), 0, st, w, u, Kc, Nc, Kc / KC, Nc / 32);
+    hipLaunchKernelGGL(k_wino_weights<FLIP>, dim3((unsigned)((Kc / 4 * Nc + 255) / 256)), dim3(256), 0, st, w, u, Kc, Nc, Kc / KC, Nc / 32);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
