@@ -165,6 +165,13 @@ int osi_conv_wgrad(const osi_conv_desc* d, const float* dy, const float* x, floa
 /* The same with x replaced by relu(x * in_scale[c] + in_shift[c]) in the loader (the conv's input activation was never stored). */
 int osi_conv_wgrad_act(const osi_conv_desc* d, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
                        void* ws, size_t ws_bytes, osi_stream_t stream);
+/* Winograd F(3x3, 2x2) form of the two calls above for 3x3 / stride 1 / pad 1 convolutions with Cin % 64 == 0 and Cout % 64 == 0
+ * (csrc/conv_wino.hip): the sum over output tiles is taken in the transformed domain (16 multiplies per tile and (cout, cin) pair
+ * instead of 36), deterministic (split-K over the tile axis into partial slabs, fixed-order reduce). in_scale / in_shift may be NULL.
+ * ws: osi_conv_wgrad_wino_workspace(d) bytes; 0 = the shape is not taken. */
+size_t osi_conv_wgrad_wino_workspace(const osi_conv_desc* d);
+int osi_conv_wgrad_wino(const osi_conv_desc* d, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
+                        void* ws, size_t ws_bytes, osi_stream_t stream);
 int osi_stem_weight_pack(const float* w_krsc3, float* w_packed, int Cout, osi_stream_t stream);
 /* Direct form of the stem weight gradient (7x7 / stride 2 / pad 3, Cout = 64, Ho % 8 == 0, Wo % 16 == 0 — the conv1 of
  * torchvision's resnet50 under model.py:17 at any image size that is a multiple of 16 x 32): writes the gradient in the PARAMETER

@@ -506,6 +506,221 @@ __global__ __launch_bounds__(64) void k_wino_fixup(WinoP p, int G) {
     }
 }
 
+// =====================================================================================================================================
+// Weight gradient, Winograd F(3x3, 2x2): the transpose of the forward algorithm.  dW = sum over tiles of  G^T [ (A dY A^T) (.) (B^T d B) ] G
+// (d = the 4x4 input patch of a tile — the SAME transform as the forward's V —, dY = the tile's 2x2 output gradients, A = the forward's
+// output-transform matrix transposed). The sum over tiles is taken in the transformed domain:
+//   S_p[cout][cin] = sum_tiles  Yt_p[cout][tile] * V_p[cin][tile],   p in 4 x 4   -> 16 GEMMs whose K axis is the TILE axis,
+// then dW[cout][.][.][cin] = G^T S G (16 -> 9 values per (cout, cin), register arithmetic in the epilogue): 16 multiplies per tile and
+// (cout, cin) pair instead of 36.
+// One workgroup = one (64 couts x 64 cins) block x one contiguous run of tiles (split-K over the tile axis: blocks x splits = the CUs);
+// every wave owns 32 x 32 of the block for all 16 positions (256 AGPRs, one wave per SIMD). K step = 8 tiles, both operands staged through
+// LDS (images [p][k-half h][channel][4 tiles]: a lane's 16-byte read = its operand of the four MFMAs of a position; 2 x 32 KiB per stage,
+// double buffered). Loader roles: wave w owns tiles {4 (w >> 1) + (w & 1), + 2} of the step for EVERY channel (lane = channel): tile
+// coordinates, image-border validity and all load offsets are SCALAR (one buffer load per pixel with the offset in an SGPR), the
+// transforms are per-lane scalar math on 2 tiles x 1 channel, 16-byte... 8-byte LDS stores.
+struct WgradP {
+    const float* x;      // conv input [B][H][W][Cin] (pre-activation when `sc`)
+    const float* dy;     // [B][H][W][Cout]
+    float* slab;         // [item][9][64][64] partial gradients, item = (kb * CBn + cb) * S + split
+    const float* sc;     // fused input activation or NULL
+    const float* sh;
+    int H, W, Cin, Cout, TH, TW, T;
+    int CBn, S, steps;   // cin blocks, splits per block, K steps (of 8 tiles) per split
+    int x_bytes, dy_bytes;
+};
+
+template <bool XF>
+__global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
+    __shared__ __attribute__((aligned(16))) float sL[2 * 2 * 16 * 2 * 64 * 4];   // [buf][operand][p][h][channel][4 tiles]: 128 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int item = blockIdx.x;
+    const int split = item % p.S, blk = item / p.S, cb = blk % p.CBn, kb = blk / p.CBn;
+    const int THW = p.TH * p.TW;
+    // loader role of this WAVE: k-half h and pair of k-pairs
+    const int lh = __builtin_amdgcn_readfirstlane(wave & 1), kkp = __builtin_amdgcn_readfirstlane(wave >> 1);
+    const uint32_t xlane = (uint32_t)((cb * 64 + lane) * 4), dlane = (uint32_t)((kb * 64 + lane) * 4);
+    const int t_first = split * p.steps * 8;
+
+    float xr[2][16], dr[2][4];
+    unsigned okx[2];                       // 16 validity bits of each tile's patch (wave-uniform)
+    f32x2 scsh = {1.f, 0.f};
+    if constexpr (XF) { scsh[0] = p.sc[cb * 64 + lane]; scsh[1] = p.sh[cb * 64 + lane]; }
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.dy, p.dy_bytes);
+    unsigned okd[2];                       // 4 validity bits of each tile's output pixels
+    // issue the loads of K step `st`: 2 tiles x (16 patch pixels of x + 4 pixels of dy). Every offset is scalar; a pixel outside the image
+    // (or a tile past the end) is read at CLAMPED coordinates — always in bounds — and selected to zero afterwards (wave-uniform bits)
+    auto load_step = [&](int st) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int tl = 4 * kkp + 2 * i2 + lh;
+            const int t_raw = __builtin_amdgcn_readfirstlane(t_first + st * 8 + tl);
+            const bool live = t_raw < p.T;
+            const int t = live ? t_raw : p.T - 1;
+            const int b = t / THW, rem = t - b * THW, th = rem / p.TW, tw = rem - th * p.TW;
+            unsigned ok = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int yy = 2 * th - 1 + i, xx = 2 * tw - 1 + j;
+                    const bool v = live && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                    const int yc = min(max(yy, 0), p.H - 1), xc = min(max(xx, 0), p.W - 1);
+                    xr[i2][i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rx, xlane, (uint32_t)(((b * p.H + yc) * p.W + xc) * p.Cin * 4), 0));
+                    ok |= v ? (1u << (i * 4 + j)) : 0u;
+                }
+            okx[i2] = ok;
+            ok = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int yy = 2 * th + i, xx = 2 * tw + j;
+                    const bool v = live && yy < p.H && xx < p.W;
+                    const int yc = min(yy, p.H - 1), xc = min(xx, p.W - 1);
+                    dr[i2][i * 2 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rd, dlane, (uint32_t)(((b * p.H + yc) * p.W + xc) * p.Cout * 4), 0));
+                    ok |= v ? (1u << (i * 2 + j)) : 0u;
+                }
+            okd[i2] = ok;
+        }
+    };
+    // LDS images. operand 0 = Yt (rows = couts), 1 = V (rows = cins); float index ((((buf * 2 + op) * 16 + pos) * 2 + h) * 64 + ch) * 4 + kk
+    auto img = [&](int buf, int op, int pos, int h, int ch) { return sL + ((((buf * 2 + op) * 16 + pos) * 2 + h) * 64 + ch) * 4; };
+    // activation of the two patches (padding / dead tiles selected to zero after it)
+    auto act = [&](int i2) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float v = XF ? fmaxf(__builtin_fmaf(xr[i2][k], scsh[0], scsh[1]), 0.f) : xr[i2][k];
+            xr[i2][k] = ((okx[i2] >> k) & 1u) ? v : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dr[i2][k] = ((okd[i2] >> k) & 1u) ? dr[i2][k] : 0.f;
+    };
+    auto col_x = [&](int i2) {      // B^T d: columns
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d0 = xr[i2][j], d1 = xr[i2][4 + j], d2 = xr[i2][8 + j], d3 = xr[i2][12 + j];
+            xr[i2][j] = d0 - d2; xr[i2][4 + j] = d1 + d2; xr[i2][8 + j] = d2 - d1; xr[i2][12 + j] = d1 - d3;
+        }
+    };
+    // (B^T d B) row i of both tiles -> V image; (A dY A^T) row i of both tiles -> Yt image. One 8-byte store per position and operand.
+    auto row_store = [&](int i, int buf) {
+        f32x2 v[4], y[4];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const float t0 = xr[i2][i * 4], t1 = xr[i2][i * 4 + 1], t2 = xr[i2][i * 4 + 2], t3 = xr[i2][i * 4 + 3];
+            v[0][i2] = t0 - t2; v[1][i2] = t1 + t2; v[2][i2] = t2 - t1; v[3][i2] = t1 - t3;
+            // A = [[1,0],[1,1],[1,-1],[0,-1]]: rows of A dY:  r0 = dy0., r1 = dy0. + dy1., r2 = dy0. - dy1., r3 = -dy1.
+            const float a = dr[i2][0], b = dr[i2][1], c = dr[i2][2], d = dr[i2][3];
+            const float e0 = i == 0 ? a : i == 1 ? a + c : i == 2 ? a - c : -c;
+            const float e1 = i == 0 ? b : i == 1 ? b + d : i == 2 ? b - d : -d;
+            y[0][i2] = e0; y[1][i2] = e0 + e1; y[2][i2] = e0 - e1; y[3][i2] = -e1;
+        }
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            *reinterpret_cast<f32x2*>(img(buf, 1, i * 4 + nu, lh, lane) + 2 * kkp) = v[nu];
+            *reinterpret_cast<f32x2*>(img(buf, 0, i * 4 + nu, lh, lane) + 2 * kkp) = y[nu];
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // prologue: step 0 into buffer 0
+    load_step(0);
+    act(0); act(1); col_x(0); col_x(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row_store(i, 0);
+    __syncthreads();
+
+    const int hh = lane >> 5, l31 = lane & 31;
+    for (int st = 0; st < p.steps; ++st) {
+        const int buf = st & 1;
+        load_step(st + 1 < p.steps ? st + 1 : st);           // the last step re-loads itself (never used): no branch around loads
+        const float* ra = img(buf, 0, 0, hh, 32 * wm + l31);
+        const float* rb = img(buf, 1, 0, hh, 32 * wn + l31);
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(ra), b0 = *reinterpret_cast<const f32x4*>(rb);
+        __builtin_amdgcn_sched_barrier(0);
+        auto position = [&](auto POSC) {
+            constexpr int pos = decltype(POSC)::value;
+            f32x4 na = a0, nb = b0;
+            if (pos < 15) {
+                na = *reinterpret_cast<const f32x4*>(ra + (pos + 1) * (2 * 64 * 4));
+                nb = *reinterpret_cast<const f32x4*>(rb + (pos + 1) * (2 * 64 * 4));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[pos], 0, 0, 0);
+            // the next step's operands: activation + column transforms behind positions 8..11, rows + LDS stores behind 12..15
+            if constexpr (pos == 8) act(0);
+            if constexpr (pos == 9) act(1);
+            if constexpr (pos == 10) col_x(0);
+            if constexpr (pos == 11) col_x(1);
+            if constexpr (pos >= 12) row_store(pos - 12, buf ^ 1);
+            a0 = na; b0 = nb;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for_each_const(position, std::make_integer_sequence<int, 16>{});
+        __syncthreads();
+    }
+
+    // ---- epilogue: dW = G^T S G per (cout, cin), written as a partial in [9][64 cout][64 cin] order (lane = cin: 128-byte runs) ---------
+    float* out = p.slab + (size_t)item * (9 * 4096) + (32 * wn + l31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hh;          // cout row of accumulator register r
+        float t[3][4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            const float s0 = acc[nu][r], s1 = acc[4 + nu][r], s2 = acc[8 + nu][r], s3 = acc[12 + nu][r];
+            t[0][nu] = s0 + 0.5f * (s1 + s2);
+            t[1][nu] = 0.5f * (s1 - s2);
+            t[2][nu] = 0.5f * (s1 + s2) + s3;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            out[(size_t)((rr * 3 + 0) * 64 + m) * 64] = t[rr][0] + 0.5f * (t[rr][1] + t[rr][2]);
+            out[(size_t)((rr * 3 + 1) * 64 + m) * 64] = 0.5f * (t[rr][1] - t[rr][2]);
+            out[(size_t)((rr * 3 + 2) * 64 + m) * 64] = 0.5f * (t[rr][1] + t[rr][2]) + t[rr][3];
+        }
+    }
+}
+
+// dW[cout][r][s][cin] = sum over the S partials of a block, fixed order (bitwise reproducible); one thread per 4 consecutive cins
+__global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int Cin, int Cout, int CBn, int S) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;           // (cout, tap, cin / 4)
+    const int C4 = Cin / 4;
+    if (idx >= Cout * 9 * C4) return;
+    const int c4 = idx % C4, tap = (idx / C4) % 9, k = idx / (C4 * 9);
+    const int cb = (c4 * 4) / 64, kb = k / 64;
+    const float* src = slab + (size_t)((kb * CBn + cb) * S) * (9 * 4096) + (size_t)(tap * 64 + (k & 63)) * 64 + ((c4 * 4) & 63);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) a += ld4(src + (size_t)s * (9 * 4096));
+    *reinterpret_cast<f32x4*>(dw + ((size_t)k * 9 + tap) * Cin + c4 * 4) = a;
+}
+
+struct WgradPlan { int S, steps; size_t slab_floats; };
+WgradPlan plan_wgrad_wino(const osi_conv_desc* d) {
+    const int T = d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+    const int blocks = (d->Cout / 64) * (d->Cin / 64);
+    int G = hw_cus();
+    int S = G / blocks;
+    if (S < 1) S = 1;
+    const int max_s = (T + 63) / 64;                 // at least 8 K steps per split
+    if (S > max_s) S = max_s;
+    const int per = (T + S - 1) / S;
+    WgradPlan w;
+    w.S = S; w.steps = (per + 7) / 8;
+    w.slab_floats = (size_t)blocks * S * 9 * 4096;
+    return w;
+}
+
 bool wino_shape(const osi_conv_desc* d) {
     return conv_desc_ok(d) && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->H == d->Ho && d->W == d->Wo && d->H >= 2 && d->W >= 2;
 }
@@ -656,6 +871,37 @@ int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const flo
         else hipLaunchKernelGGL((k_wino_fixup<1, false>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
         OSI_LAUNCH_CHECK();
     }
+    return OSI_OK;
+}
+
+/* Winograd F(3x3, 2x2) twin of osi_conv_wgrad / osi_conv_wgrad_act (in_scale / in_shift NULL: plain input) for 3x3 / stride 1 / pad 1
+ * convolutions with Cin % 64 == 0 and Cout % 64 == 0: 2.25x fewer multiplies, deterministic (split-K over the tile axis into partial
+ * slabs, fixed-order reduce). ws: osi_conv_wgrad_wino_workspace(d) bytes (0 = shape not taken). */
+size_t osi_conv_wgrad_wino_workspace(const osi_conv_desc* d) {
+    if (!wino_shape(d) || d->Cin % 64 || d->Cout % 64) return 0;
+    return plan_wgrad_wino(d).slab_floats * sizeof(float);
+}
+
+int osi_conv_wgrad_wino(const osi_conv_desc* d, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
+                        void* ws, size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(dy && x && dw && ws && wino_shape(d) && d->Cin % 64 == 0 && d->Cout % 64 == 0);
+    OSI_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
+    const WgradPlan w = plan_wgrad_wino(d);
+    OSI_REQUIRE(ws_bytes >= w.slab_floats * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    WgradP p{};
+    p.x = x; p.dy = dy; p.slab = (float*)ws; p.sc = in_scale; p.sh = in_shift;
+    p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.TH = (d->H + 1) / 2; p.TW = (d->W + 1) / 2; p.T = d->B * p.TH * p.TW;
+    p.CBn = d->Cin / 64; p.S = w.S; p.steps = w.steps;
+    p.x_bytes = (int)((size_t)d->B * d->H * d->W * d->Cin * 4);
+    p.dy_bytes = (int)((size_t)d->B * d->H * d->W * d->Cout * 4);
+    const dim3 grid((unsigned)((d->Cout / 64) * p.CBn * p.S)), blk(256);
+    if (in_scale) hipLaunchKernelGGL((k_wino_wgrad<true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((k_wino_wgrad<false>), grid, blk, 0, st, p);
+    OSI_LAUNCH_CHECK();
+    const int n = d->Cout * 9 * (d->Cin / 4);
+    hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3((unsigned)((n + 255) / 256)), blk, 0, st, (const float*)ws, dw, d->Cin, d->Cout, p.CBn, p.S);
+    OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
 

@@ -187,3 +187,47 @@ def test_executor_takes_the_winograd_forms(cuda):
         N.check(L.osi_set_tuning(b"dgrad_wino", 1))
     assert float((outs[1][0] - outs[0][0]).abs().max()) <= 5e-5
     assert not torch.equal(outs[1][0], outs[0][0]), "the two executors run different conv2 kernels"
+
+
+def _wgrad(cuda, B, H, W, Cin, Cout, act, seed):
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    g = _gen(cuda, "wino-wgrad", seed, B, H, W, Cin, Cout, act)
+    d = N.ConvDesc.make(B, H, W, Cin, Cout, 3, 1, 1)
+    nb = L.osi_conv_wgrad_wino_workspace(ctypes.byref(d))
+    assert nb > 0
+    x = torch.randn(B, H, W, Cin, device=cuda, generator=g) * 1.2 + 0.3
+    dy = torch.randn(B, H, W, Cout, device=cuda, generator=g)
+    a64 = _cpu64(x)
+    sc = sh = None
+    if act:
+        sc, sh = torch.rand(Cin, device=cuda, generator=g) + 0.5, torch.randn(Cin, device=cuda, generator=g) * 0.5
+        a64 = torch.relu(a64 * _cpu64(sc) + _cpu64(sh))
+    ws = torch.empty(nb, dtype=torch.uint8, device=cuda)
+    dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=cuda)
+    N.check(L.osi_conv_wgrad_wino(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc) if act else None, N.ptr(sh) if act else None, N.ptr(dw), N.ptr(ws), nb,
+                                  T.S()), "osi_conv_wgrad_wino")
+    ref = torch.nn.grad.conv2d_weight(T.nchw(a64), (Cout, Cin, 3, 3), T.nchw(_cpu64(dy)), 1, 1).permute(0, 2, 3, 1)
+    err = float((_cpu64(dw) - ref).abs().max())
+    Kp = B * H * W
+    assert err <= _bound(Kp, ref), f"{(B, H, W, Cin, Cout)}: {err:.3e} > {_bound(Kp, ref):.3e}"
+    dw2 = torch.full_like(dw, float("nan"))
+    N.check(L.osi_conv_wgrad_wino(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc) if act else None, N.ptr(sh) if act else None, N.ptr(dw2), N.ptr(ws), nb,
+                                  T.S()))
+    assert torch.equal(dw, dw2), "split-K over the tile axis with a fixed-order reduce: bitwise reproducible"
+    return err
+
+
+@pytest.mark.parametrize("C,H", NETWORK)
+def test_weight_gradient_network_shapes_at_the_benchmarked_batch(cuda, C, H):
+    """osi_conv_wgrad_wino as the executor issues it for conv2 (fused input activation) against torch-CPU fp64 conv2d_weight under the
+    per-kernel bound of the direct weight-gradient kernels (K = the pixels summed over)."""
+    _wgrad(cuda, 128, H, H, C, C, True, 0)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act", [(6, 7, 7, 64, 128, True),      # tiles over the border, a ragged last K step
+                                                (3, 14, 14, 128, 64, False),   # plain input; 147 tiles
+                                                (5, 10, 6, 64, 64, True)])     # non-square
+def test_weight_gradient_ragged_and_odd_geometries(cuda, B, H, W, Cin, Cout, act):
+    _wgrad(cuda, B, H, W, Cin, Cout, act, 1)

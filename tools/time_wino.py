@@ -30,7 +30,7 @@ def bench(fn):
     return sorted(best)[2]
 
 
-print(f"B={B}: us per launch (direct-conv TFLOP/s)   fwd direct | fwd wino | dgrad direct | dgrad wino")
+print(f"B={B}: us per launch (direct-conv TFLOP/s)   fwd direct | fwd wino | dgrad direct | dgrad wino | wgrad direct | wgrad wino")
 for C, H in [(64, 56), (128, 28), (256, 14), (512, 7)]:
     d = N.ConvDesc.make(B, H, H, C, C, 3, 1, 1)
     M = B * H * H
@@ -51,9 +51,14 @@ for C, H in [(64, 56), (128, 28), (256, 14), (512, 7)]:
         "dd": lambda: N.check(L.osi_conv_dgrad_fused(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(dx), None, ctypes.byref(f), 0, ctypes.byref(P), st)),
         "dw": lambda: N.check(L.osi_conv_dgrad_fused_wino(ctypes.byref(d), N.ptr(dy), N.ptr(w), N.ptr(dx), ctypes.byref(f), N.ptr(ws), wb, ctypes.byref(P), st)),
     }
+    gb = L.osi_conv_wgrad_workspace(ctypes.byref(d)); gws = torch.empty(max(gb, 16), dtype=torch.uint8, device=dev)
+    gwb = L.osi_conv_wgrad_wino_workspace(ctypes.byref(d)); gwws = torch.empty(max(gwb, 16), dtype=torch.uint8, device=dev)
+    dw = torch.empty(C, 3, 3, C, device=dev)
+    fns["gd"] = lambda: N.check(L.osi_conv_wgrad_act(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(dw), N.ptr(gws), gb, st))
+    fns["gw"] = lambda: N.check(L.osi_conv_wgrad_wino(ctypes.byref(d), N.ptr(dy), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(dw), N.ptr(gwws), gwb, st))
     gf = 2.0 * M * C * C * 9 / 1e6
     out = []
-    for k in ("fd", "fw", "dd", "dw"):
+    for k in ("fd", "fw", "dd", "dw", "gd", "gw"):
         if (only == "wino" and k[1] != "w") or (only == "direct" and k[1] != "d"):
             out.append("      -      "); continue
         ms = bench(fns[k])
