@@ -1475,7 +1475,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
             // The validity of (pixel, tap (r, s)) is rowm(pixel, r) & colm(pixel, s): the row part goes onto the dY operand (two masked
             // copies of a0 / a1), the column part onto the six X operands of s = 0 and s = 2 — four sign-extended bit fields and ten
             // v_and per K step instead of a bit test, a compare and a select per tap (27; tools/probes/wgrad3_ablate.sh priced the
-            // tap mask at 17 - 20 % of the kernel).
+            // tap mask at 17 - 20 % of the kernel). Consequence, accepted: a masked-out tap of the centre column (s = 1) multiplies 0 (dY side) by
+            // the X value instead of dY by 0 (X side), so a non-finite activation (Inf / NaN) at a pixel whose tap row is out of the image
+            // puts NaN into that weight gradient where the select form gave 0 — as the reference's own conv2d_weight does for a non-finite
+            // input (0 * Inf): a network whose activations are finite (every tested one) sees no difference.
             auto mma_ops = [&](const Ops& o) {
                 const uint32_t mr0 = (uint32_t)((int)(o.m << 30) >> 31), mr2 = (uint32_t)((int)(o.m << 24) >> 31);   // bits 1, 7: taps (0,1), (2,1)
                 const uint32_t ms0 = (uint32_t)((int)(o.m << 28) >> 31), ms2 = (uint32_t)((int)(o.m << 26) >> 31);   // bits 3, 5: taps (1,0), (1,2)

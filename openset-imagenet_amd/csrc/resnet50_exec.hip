@@ -196,7 +196,7 @@ struct osi_resnet50 {
         return plan_hw_cus == device_cus() && a.wgrad_tile == b.wgrad_tile && a.wgrad_blocks == b.wgrad_blocks && a.wgrad3 == b.wgrad3 && a.wgrad3_blocks == b.wgrad3_blocks &&
                a.tail_split == b.tail_split && a.tail_cus == b.tail_cus && a.tail_smax == b.tail_smax && a.tail_mint == b.tail_mint &&
                a.tail_gain == b.tail_gain && a.tail_qmax == b.tail_qmax && a.stem_direct == b.stem_direct && a.wgrad_group == b.wgrad_group &&
-               a.dp_reserved_cus == b.dp_reserved_cus && a.fwd_wino == b.fwd_wino && a.dgrad_wino == b.dgrad_wino;
+               a.dp_reserved_cus == b.dp_reserved_cus && a.fwd_wino == b.fwd_wino && a.dgrad_wino == b.dgrad_wino && a.wgrad_wino == b.wgrad_wino;
     }
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wdone = nullptr, ev_rmain = nullptr, ev_rside = nullptr;
@@ -320,6 +320,8 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
         size_t wg = osi_conv_wgrad_workspace(&c.d);
         if (wg > wgws) wgws = wg;
         wg = osi_stem_wgrad_direct_workspace(&c.d);
+        if (wg > wgws) wgws = wg;
+        wg = osi_conv_wgrad_wino_workspace(&c.d);
         if (wg > wgws) wgws = wg;
         if (!(c.d.Cin == 4 && c.d.R == 7)) { size_t dg = osi_conv_dgrad_fused_workspace(&c.d); if (dg > dgws) dgws = dg; }
         if (osi_conv_wino_eligible(&c.d, 0) || osi_conv_wino_eligible(&c.d, 1)) {
@@ -608,6 +610,10 @@ static int wgrad_launch(osi_resnet50* n, int ci, float* grads, float* ws, int gi
             OSI_TRY(osi_conv_wgrad(&c.d, dy, conv_in, ws + n->gpack, ws + n->wg_ws, n->wg_ws_bytes, ws_st));
             OSI_TRY(osi_stem_grad_unpack(ws + n->gpack, grads + c.w_off, 64, ws_st));
         }
+    } else if (in_bn >= 0 && n->plan_knobs.wgrad_wino && osi_conv_wgrad_wino_workspace(&c.d) > 0) {
+        // 3x3 / stride 1 (conv2 of a bottleneck without a stride): Winograd F(3x3, 2x2), the sum over tiles in the transformed domain
+        OSI_TRY(osi_conv_wgrad_wino(&c.d, dy, conv_in, ws + n->bns[in_bn].scale, ws + n->bns[in_bn].shift, grads + c.w_off, ws + n->wg_ws,
+                                    n->wg_ws_bytes, ws_st));
     } else if (in_bn >= 0) {
         OSI_TRY(osi_conv_wgrad_act(&c.d, dy, conv_in, ws + n->bns[in_bn].scale, ws + n->bns[in_bn].shift, grads + c.w_off, ws + n->wg_ws,
                                    n->wg_ws_bytes, ws_st));

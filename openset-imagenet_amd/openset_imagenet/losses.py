@@ -55,13 +55,26 @@ class _LossValue(torch.Tensor):
     dJ/dlogits (and dJ/dfeatures) — already computed by the loss kernel — go straight to the network's backward instead of
     through autograd's seed gradient (a ones_like fill) and a `dlogits * 1` multiply: two elementwise launches fewer between the
     forward and the backward pass. Every other use (gradient=, inputs=, retain_graph, create_graph, or a loss that was combined
-    with other terms and therefore is a new tensor) takes the ordinary autograd route, which gives the same gradients."""
+    with other terms and therefore is a new tensor) takes the ordinary autograd route, which gives the same gradients.
+
+    Divergence from `torch.Tensor.backward`, by design: the direct route does not run autograd, so it is taken only when nothing could
+    observe the difference — logits / features carry no tensor hooks and do not retain their gradient (otherwise: the autograd route) —
+    and it consumes the loss: a second plain `backward()` of the same loss raises a clear error, as torch's own "backward through the
+    graph a second time" would."""
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        if self.__dict__.get("_osi_consumed"):
+            raise RuntimeError("backward() was already called on this loss: the network's activations of that forward have been consumed "
+                               "(run the forward pass again — the reference loop does, train.py:132-139)")
         direct = self.__dict__.pop("_osi_direct", None)
+        if direct is not None:
+            watched = any(t is not None and (t.retains_grad or bool(getattr(t, "_backward_hooks", None))) for t in direct[2])
+            if watched:
+                direct = None
         if direct is None or gradient is not None or retain_graph or create_graph or inputs is not None:
             return super().backward(gradient, retain_graph, create_graph, inputs)
-        node, fn = direct
+        node, fn, _ = direct
+        self.__dict__["_osi_consumed"] = True
         model = node.model
         if node.serial != model._fwd_serial:
             raise RuntimeError("backward() of a forward pass that is no longer the model's latest one: the executor keeps the "
@@ -78,7 +91,7 @@ def _loss_value(j, logits, features=None):
     if features is not None and features.grad_fn is not node:
         return j
     out = j.as_subclass(_LossValue)
-    out._osi_direct = (node, j.grad_fn)
+    out._osi_direct = (node, j.grad_fn, (logits, features))
     return out
 
 
