@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1, /*tail_gain*/ 8, /*tail_qmax*/ 8, /*bn_grid_bwd*/ 1024, /*bn_wide_p*/ 2048, /*fwd_rows*/ 1, /*fwd_w3*/ 1, /*dgrad_w3*/ 1, /*fwd_wino*/ 1, /*dgrad_wino*/ 1, /*wgrad_wino*/ 0, /*wino_streamk*/ 1, /*dp_reserved_cus*/ 0};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1, /*tail_gain*/ 8, /*tail_qmax*/ 8, /*bn_grid_bwd*/ 1024, /*bn_wide_p*/ 2048, /*fwd_rows*/ 1, /*fwd_w3*/ 1, /*dgrad_w3*/ 1, /*fwd_wino*/ 1, /*dgrad_wino*/ 1, /*wgrad_wino*/ 1, /*wino_streamk*/ 1, /*dp_reserved_cus*/ 0};
 
 namespace {
 int* tuning_slot(const char* name) {

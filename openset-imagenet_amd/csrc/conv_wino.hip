@@ -36,6 +36,10 @@ using namespace osi_conv;
 
 namespace {
 
+// diagnostic builds of the weight-gradient kernel only (tools): 1 = no operand loads inside the K loop, 2 = no transform / LDS stores (wrong results)
+#ifndef OSI_WABL
+#define OSI_WABL 0
+#endif
 constexpr int KC = 16;      // channels per K slice
 constexpr int PF = 6;       // positions the U fragments are loaded ahead
 
@@ -528,6 +532,7 @@ struct WgradP {
     int H, W, Cin, Cout, TH, TW, T;
     int CBn, S, steps;   // cin blocks, splits per block, K steps (of 8 tiles) per split
     int x_bytes, dy_bytes;
+    FastDiv dTHW, dTW;
 };
 
 template <bool XF>
@@ -536,86 +541,101 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int item = blockIdx.x;
     const int split = item % p.S, blk = item / p.S, cb = blk % p.CBn, kb = blk / p.CBn;
-    const int THW = p.TH * p.TW;
     // loader role of this WAVE: k-half h and pair of k-pairs
     const int lh = __builtin_amdgcn_readfirstlane(wave & 1), kkp = __builtin_amdgcn_readfirstlane(wave >> 1);
     const uint32_t xlane = (uint32_t)((cb * 64 + lane) * 4), dlane = (uint32_t)((kb * 64 + lane) * 4);
     const int t_first = split * p.steps * 8;
-
-    float xr[2][16], dr[2][4];
-    unsigned okx[2];                       // 16 validity bits of each tile's patch (wave-uniform)
-    f32x2 scsh = {1.f, 0.f};
-    if constexpr (XF) { scsh[0] = p.sc[cb * 64 + lane]; scsh[1] = p.sh[cb * 64 + lane]; }
-
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.dy, p.dy_bytes);
-    unsigned okd[2];                       // 4 validity bits of each tile's output pixels
-    // issue the loads of K step `st`: 2 tiles x (16 patch pixels of x + 4 pixels of dy). Every offset is scalar; a pixel outside the image
-    // (or a tile past the end) is read at CLAMPED coordinates — always in bounds — and selected to zero afterwards (wave-uniform bits)
-    auto load_step = [&](int st) {
+    f32x2 scsh = {1.f, 0.f};
+    if constexpr (XF) { scsh[0] = p.sc[cb * 64 + lane]; scsh[1] = p.sh[cb * 64 + lane]; }
+    const int cin4 = p.Cin * 4, cout4 = p.Cout * 4;
+
+    // Loads of a K step. Every offset is SCALAR (lane = channel): a pixel outside the image (or a tile past the end) is read at clamped
+    // coordinates — always in bounds — and selected to zero afterwards by wave-uniform bits. Offsets are separable: byte offset of patch
+    // pixel (i, j) = row part [i] (image base included) + column part [j]. prep_step computes the scalars of a step, issue_load<n> issues its
+    // n-th load (0..39: tile n / 20, patch pixel n % 20 or dy pixel n % 20 - 16): a burst of 40 one-dword loads per wave blocks at the
+    // texture addresser's queue (4 waves x 40 x 256 B: ~0.9 us per step, measured), spread over the positions of a step it is free.
+    // raw operands of this wave, two register sets — 0: the step being transformed, 1: the step in flight —: 2 tiles x (16 patch pixels of x,
+    // 4 pixels of dy) for the lane's channel + wave-uniform validity bits. Indexed by compile-time constants only.
+    float rx_[2][2][16], rd_[2][2][4];
+    unsigned okx_[2][2], okd_[2][2];
+    uint32_t srb[2][4], scb[2][4], sdr[2][2], sdc[2][2];
+    auto prep_step = [&](int st, auto SETC) {
+        constexpr int set = decltype(SETC)::value;
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
             const int tl = 4 * kkp + 2 * i2 + lh;
             const int t_raw = __builtin_amdgcn_readfirstlane(t_first + st * 8 + tl);
             const bool live = t_raw < p.T;
-            const int t = live ? t_raw : p.T - 1;
-            const int b = t / THW, rem = t - b * THW, th = rem / p.TW, tw = rem - th * p.TW;
+            const uint32_t t = (uint32_t)(live ? t_raw : p.T - 1);
+            const uint32_t b = fdiv(t, p.dTHW), rem = t - b * p.dTHW.d, th = fdiv(rem, p.dTW), tw = rem - th * p.dTW.d;
+            const int y0 = 2 * (int)th - 1, x0 = 2 * (int)tw - 1;
+            unsigned rok = 0, cok = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yy = y0 + i, xx = x0 + i;
+                rok |= ((unsigned)yy < (unsigned)p.H) ? (1u << i) : 0u;
+                cok |= ((unsigned)xx < (unsigned)p.W) ? (1u << i) : 0u;
+                srb[i2][i] = (uint32_t)((((int)b * p.H + min(max(yy, 0), p.H - 1)) * p.W) * cin4);
+                scb[i2][i] = (uint32_t)(min(max(xx, 0), p.W - 1) * cin4);
+            }
+            if (!live) rok = 0;
             unsigned ok = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) ok |= ((rok >> i) & 1u) ? (cok << (4 * i)) : 0u;
+            okx_[set][i2] = ok;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int yy = 2 * th - 1 + i, xx = 2 * tw - 1 + j;
-                    const bool v = live && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                    const int yc = min(max(yy, 0), p.H - 1), xc = min(max(xx, 0), p.W - 1);
-                    xr[i2][i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rx, xlane, (uint32_t)(((b * p.H + yc) * p.W + xc) * p.Cin * 4), 0));
-                    ok |= v ? (1u << (i * 4 + j)) : 0u;
-                }
-            okx[i2] = ok;
-            ok = 0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int yy = 2 * th + i, xx = 2 * tw + j;
-                    const bool v = live && yy < p.H && xx < p.W;
-                    const int yc = min(yy, p.H - 1), xc = min(xx, p.W - 1);
-                    dr[i2][i * 2 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rd, dlane, (uint32_t)(((b * p.H + yc) * p.W + xc) * p.Cout * 4), 0));
-                    ok |= v ? (1u << (i * 2 + j)) : 0u;
-                }
-            okd[i2] = ok;
+            for (int i = 0; i < 2; ++i) {
+                sdr[i2][i] = (uint32_t)(((int)b * p.H + min(y0 + 1 + i, p.H - 1)) * p.W) * (uint32_t)cout4;
+                sdc[i2][i] = (uint32_t)min(x0 + 1 + i, p.W - 1) * (uint32_t)cout4;
+            }
+            okd_[set][i2] = (((rok >> 1) & 1u) ? ((cok >> 1) & 3u) : 0u) | (((rok >> 2) & 1u) ? (((cok >> 1) & 3u) << 2) : 0u);
         }
+    };
+    auto issue_load = [&](auto NC, auto SETC) {
+        constexpr int n = decltype(NC)::value, set = decltype(SETC)::value, i2 = n / 20, k = n % 20;
+        if constexpr (k < 16)
+            rx_[set][i2][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xlane, srb[i2][k / 4] + scb[i2][k % 4], 0));
+        else
+            rd_[set][i2][k - 16] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, dlane, sdr[i2][(k - 16) / 2] + sdc[i2][(k - 16) % 2], 0));
+    };
+    auto load_step = [&](int st, auto SETC) {       // the whole step at once (prologue)
+        prep_step(st, SETC);
+        auto one = [&](auto NC) { issue_load(NC, SETC); };
+        for_each_const(one, std::make_integer_sequence<int, 40>{});
     };
     // LDS images. operand 0 = Yt (rows = couts), 1 = V (rows = cins); float index ((((buf * 2 + op) * 16 + pos) * 2 + h) * 64 + ch) * 4 + kk
     auto img = [&](int buf, int op, int pos, int h, int ch) { return sL + ((((buf * 2 + op) * 16 + pos) * 2 + h) * 64 + ch) * 4; };
-    // activation of the two patches (padding / dead tiles selected to zero after it)
-    auto act = [&](int i2) {
+    // activation of a tile's patch (padding / dead tiles selected to zero after it) and zeroing of dy pixels outside the image
+    auto act = [&](auto SETC, int i2) {
+        constexpr int set = decltype(SETC)::value;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const float v = XF ? fmaxf(__builtin_fmaf(xr[i2][k], scsh[0], scsh[1]), 0.f) : xr[i2][k];
-            xr[i2][k] = ((okx[i2] >> k) & 1u) ? v : 0.f;
+            const float v = XF ? fmaxf(__builtin_fmaf(rx_[set][i2][k], scsh[0], scsh[1]), 0.f) : rx_[set][i2][k];
+            rx_[set][i2][k] = ((okx_[set][i2] >> k) & 1u) ? v : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dr[i2][k] = ((okd[i2] >> k) & 1u) ? dr[i2][k] : 0.f;
+        for (int k = 0; k < 4; ++k) rd_[set][i2][k] = ((okd_[set][i2] >> k) & 1u) ? rd_[set][i2][k] : 0.f;
     };
-    auto col_x = [&](int i2) {      // B^T d: columns
+    auto col_x = [&](auto SETC, int i2) {      // B^T d: columns
+        constexpr int set = decltype(SETC)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float d0 = xr[i2][j], d1 = xr[i2][4 + j], d2 = xr[i2][8 + j], d3 = xr[i2][12 + j];
-            xr[i2][j] = d0 - d2; xr[i2][4 + j] = d1 + d2; xr[i2][8 + j] = d2 - d1; xr[i2][12 + j] = d1 - d3;
+            const float d0 = rx_[set][i2][j], d1 = rx_[set][i2][4 + j], d2 = rx_[set][i2][8 + j], d3 = rx_[set][i2][12 + j];
+            rx_[set][i2][j] = d0 - d2; rx_[set][i2][4 + j] = d1 + d2; rx_[set][i2][8 + j] = d2 - d1; rx_[set][i2][12 + j] = d1 - d3;
         }
     };
     // (B^T d B) row i of both tiles -> V image; (A dY A^T) row i of both tiles -> Yt image. One 8-byte store per position and operand.
-    auto row_store = [&](int i, int buf) {
+    auto row_store = [&](auto SETC, int i, int buf) {
+        constexpr int set = decltype(SETC)::value;
         f32x2 v[4], y[4];
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
-            const float t0 = xr[i2][i * 4], t1 = xr[i2][i * 4 + 1], t2 = xr[i2][i * 4 + 2], t3 = xr[i2][i * 4 + 3];
+            const float t0 = rx_[set][i2][i * 4], t1 = rx_[set][i2][i * 4 + 1], t2 = rx_[set][i2][i * 4 + 2], t3 = rx_[set][i2][i * 4 + 3];
             v[0][i2] = t0 - t2; v[1][i2] = t1 + t2; v[2][i2] = t2 - t1; v[3][i2] = t1 - t3;
             // A = [[1,0],[1,1],[1,-1],[0,-1]]: rows of A dY:  r0 = dy0., r1 = dy0. + dy1., r2 = dy0. - dy1., r3 = -dy1.
-            const float a = dr[i2][0], b = dr[i2][1], c = dr[i2][2], d = dr[i2][3];
+            const float a = rd_[set][i2][0], b = rd_[set][i2][1], c = rd_[set][i2][2], d = rd_[set][i2][3];
             const float e0 = i == 0 ? a : i == 1 ? a + c : i == 2 ? a - c : -c;
             const float e1 = i == 0 ? b : i == 1 ? b + d : i == 2 ? b - d : -d;
             y[0][i2] = e0; y[1][i2] = e0 + e1; y[2][i2] = e0 - e1; y[3][i2] = -e1;
@@ -633,17 +653,40 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // prologue: step 0 into buffer 0
-    load_step(0);
-    act(0); act(1); col_x(0); col_x(1);
+    // prologue: step 0 transformed into buffer 0, step 1 in flight. The loads run TWO steps ahead of the MFMAs (a step is 16 x 4 MFMAs =
+    // 1.7 us: one step of lead does not cover an HBM round trip when a lone wave per SIMD has nothing else to run), in two register sets.
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    load_step(0, S0{});
+    load_step(p.steps > 1 ? 1 : 0, S1{});
+    act(S0{}, 0); act(S0{}, 1); col_x(S0{}, 0); col_x(S0{}, 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) row_store(i, 0);
+    for (int i = 0; i < 4; ++i) row_store(S0{}, i, 0);
     __syncthreads();
 
     const int hh = lane >> 5, l31 = lane & 31;
+    // One K step st: MFMAs on LDS buffer st & 1 while the operands of step st + 1 are transformed into the other buffer (behind positions
+    // TR0..15) and the loads of step st + 2 are in flight. The loads need TWO steps of lead: a step is 16 x 4 MFMAs = 1.7 us, every byte of
+    // the 64-channel layers comes from HBM exactly once (~2 us under load), and a lone wave per SIMD has nothing else to run — with one
+    // step of lead the kernel waited 0.9 us per step (ablation: 190 -> 146 us without the loads). Two register sets that swap roles would
+    // need the loop unrolled by two (the register allocator then shuffles the 256 accumulators between the copies: 170 spills), so set 1
+    // (in flight, a full step old) is COPIED into set 0 at the top of a step — 44 moves — and re-loaded.
+    constexpr int TR0 = 10;
     for (int st = 0; st < p.steps; ++st) {
         const int buf = st & 1;
-        load_step(st + 1 < p.steps ? st + 1 : st);           // the last step re-loads itself (never used): no branch around loads
+        {   // set 1 holds step st + 1 (loaded a full step ago): into set 0
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) rx_[0][i2][k] = rx_[1][i2][k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rd_[0][i2][k] = rd_[1][i2][k];
+                okx_[0][i2] = okx_[1][i2]; okd_[0][i2] = okd_[1][i2];
+            }
+        }
+#if !(OSI_WABL & 1)
+        prep_step(st + 2 < p.steps ? st + 2 : p.steps - 1, S1{});   // past the end: a valid step re-loaded (never used): no branch around loads
+#endif
         const float* ra = img(buf, 0, 0, hh, 32 * wm + l31);
         const float* rb = img(buf, 1, 0, hh, 32 * wn + l31);
         f32x4 a0 = *reinterpret_cast<const f32x4*>(ra), b0 = *reinterpret_cast<const f32x4*>(rb);
@@ -657,12 +700,19 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[pos], 0, 0, 0);
-            // the next step's operands: activation + column transforms behind positions 8..11, rows + LDS stores behind 12..15
-            if constexpr (pos == 8) act(0);
-            if constexpr (pos == 9) act(1);
-            if constexpr (pos == 10) col_x(0);
-            if constexpr (pos == 11) col_x(1);
-            if constexpr (pos >= 12) row_store(pos - 12, buf ^ 1);
+#if !(OSI_WABL & 1)
+            {   // this position's share of the step-after-next's 40 loads
+                constexpr int n0 = pos * 40 / 16, n1 = (pos + 1) * 40 / 16;
+                if constexpr (n1 > n0) issue_load(std::integral_constant<int, n0>{}, S1{});
+                if constexpr (n1 > n0 + 1) issue_load(std::integral_constant<int, n0 + 1>{}, S1{});
+                if constexpr (n1 > n0 + 2) issue_load(std::integral_constant<int, n0 + 2>{}, S1{});
+            }
+#endif
+#if !(OSI_WABL & 2)
+            if constexpr (pos == TR0) { act(S0{}, 0); act(S0{}, 1); }
+            if constexpr (pos == TR0 + 1) { col_x(S0{}, 0); col_x(S0{}, 1); }
+            if constexpr (pos >= 12) row_store(S0{}, pos - 12, buf ^ 1);
+#endif
             a0 = na; b0 = nb;
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -692,17 +742,30 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
     }
 }
 
-// dW[cout][r][s][cin] = sum over the S partials of a block, fixed order (bitwise reproducible); one thread per 4 consecutive cins
-__global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int Cin, int Cout, int CBn, int S) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;           // (cout, tap, cin / 4)
-    const int C4 = Cin / 4;
-    if (idx >= Cout * 9 * C4) return;
-    const int c4 = idx % C4, tap = (idx / C4) % 9, k = idx / (C4 * 9);
-    const int cb = (c4 * 4) / 64, kb = k / 64;
-    const float* src = slab + (size_t)((kb * CBn + cb) * S) * (9 * 4096) + (size_t)(tap * 64 + (k & 63)) * 64 + ((c4 * 4) & 63);
+// dW[cout][r][s][cin] = sum over the S partials of a block, in a FIXED order (bitwise reproducible): SG split groups per output (a
+// power of two <= 16: 256 partials of the 64-channel layers would otherwise be one thread's serial chain on 36 workgroups), group g sums
+// the partials s = g, g + SG, ..., the groups are added in group order through LDS. One thread per (4 consecutive cins, group).
+__global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int Cin, int Cout, int CBn, int S,
+                                                           int SG) {
+    __shared__ f32x4 part[256];
+    const int per = 256 / SG;                                  // outputs (of 4 floats) per workgroup
+    const int o = threadIdx.x % per, g = threadIdx.x / per;
+    const int idx = blockIdx.x * per + o;                      // (cout, tap, cin / 4)
+    const int C4 = Cin / 4, n = Cout * 9 * C4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < S; ++s) a += ld4(src + (size_t)s * (9 * 4096));
-    *reinterpret_cast<f32x4*>(dw + ((size_t)k * 9 + tap) * Cin + c4 * 4) = a;
+    int k = 0, tap = 0, c4 = 0;
+    if (idx < n) {
+        c4 = idx % C4; tap = (idx / C4) % 9; k = idx / (C4 * 9);
+        const int cb = (c4 * 4) / 64, kb = k / 64;
+        const float* src = slab + (size_t)((kb * CBn + cb) * S) * (9 * 4096) + (size_t)(tap * 64 + (k & 63)) * 64 + ((c4 * 4) & 63);
+        for (int s = g; s < S; s += SG) a += ld4(src + (size_t)s * (9 * 4096));
+    }
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (g == 0 && idx < n) {
+        for (int j = 1; j < SG; ++j) a += part[j * per + o];
+        *reinterpret_cast<f32x4*>(dw + ((size_t)k * 9 + tap) * Cin + c4 * 4) = a;
+    }
 }
 
 struct WgradPlan { int S, steps; size_t slab_floats; };
@@ -893,6 +956,7 @@ int osi_conv_wgrad_wino(const osi_conv_desc* d, const float* dy, const float* x,
     p.x = x; p.dy = dy; p.slab = (float*)ws; p.sc = in_scale; p.sh = in_shift;
     p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.TH = (d->H + 1) / 2; p.TW = (d->W + 1) / 2; p.T = d->B * p.TH * p.TW;
     p.CBn = d->Cin / 64; p.S = w.S; p.steps = w.steps;
+    p.dTHW = make_fastdiv((uint32_t)(p.TH * p.TW)); p.dTW = make_fastdiv((uint32_t)p.TW);
     p.x_bytes = (int)((size_t)d->B * d->H * d->W * d->Cin * 4);
     p.dy_bytes = (int)((size_t)d->B * d->H * d->W * d->Cout * 4);
     const dim3 grid((unsigned)((d->Cout / 64) * p.CBn * p.S)), blk(256);
@@ -900,7 +964,10 @@ int osi_conv_wgrad_wino(const osi_conv_desc* d, const float* dy, const float* x,
     else hipLaunchKernelGGL((k_wino_wgrad<false>), grid, blk, 0, st, p);
     OSI_LAUNCH_CHECK();
     const int n = d->Cout * 9 * (d->Cin / 4);
-    hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3((unsigned)((n + 255) / 256)), blk, 0, st, (const float*)ws, dw, d->Cin, d->Cout, p.CBn, p.S);
+    int SG = 1;
+    while (SG * 2 <= p.S && SG < 16) SG *= 2;
+    const int per = 256 / SG;
+    hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3((unsigned)((n + per - 1) / per)), blk, 0, st, (const float*)ws, dw, d->Cin, d->Cout, p.CBn, p.S, SG);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }

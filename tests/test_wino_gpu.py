@@ -163,7 +163,7 @@ def test_executor_takes_the_winograd_forms(cuda):
     from openset_imagenet import ResNet50, EntropicOpensetLoss, tools, _native as N
     L = N.lib()
     v = ctypes.c_int()
-    for k in (b"fwd_wino", b"dgrad_wino"):
+    for k in (b"fwd_wino", b"dgrad_wino", b"wgrad_wino"):
         N.check(L.osi_get_tuning(k, ctypes.byref(v)))
         assert v.value == 1
     outs = {}
@@ -171,6 +171,7 @@ def test_executor_takes_the_winograd_forms(cuda):
         for mode in (1, 0):
             N.check(L.osi_set_tuning(b"fwd_wino", mode))
             N.check(L.osi_set_tuning(b"dgrad_wino", mode))
+            N.check(L.osi_set_tuning(b"wgrad_wino", mode))
             tools.set_device_gpu(0)
             torch.manual_seed(3)
             model = tools.device(ResNet50(10, 10, False))
@@ -185,6 +186,11 @@ def test_executor_takes_the_winograd_forms(cuda):
     finally:
         N.check(L.osi_set_tuning(b"fwd_wino", 1))
         N.check(L.osi_set_tuning(b"dgrad_wino", 1))
+        N.check(L.osi_set_tuning(b"wgrad_wino", 1))
+    # weight gradients of the two executors: the same sums in another order
+    for k in outs[0][1]:
+        a, b = outs[1][1][k], outs[0][1][k]
+        assert float((a - b).norm() / (b.norm() + 1e-30)) <= 2e-2, k       # free-running: a few ReLU decisions may differ
     assert float((outs[1][0] - outs[0][0]).abs().max()) <= 5e-5
     assert not torch.equal(outs[1][0], outs[0][0]), "the two executors run different conv2 kernels"
 
