@@ -692,7 +692,10 @@ def main():
                                 "rocprofv3 PMC summary named in traffic_provenance (--pmc FETCH_SIZE / WRITE_SIZE, separate passes); null "
                                 "when that profile was taken on another workload or its step time is >15% off this run (stale); "
                                 "algorithmic minimum ~36e9 (each conv input/output once fwd, dY+W / dY+X bwd)",
-                "kernel": "implicit-GEMM conv (k_conv_fwd + k_conv_dgrad + k_conv_wgrad incl. split-K reduce), fp32 MFMA 32x32x2",
+                "kernel": "conv stack, fp32 MFMA 32x32x2: implicit GEMM (k_conv_fwd + k_conv_dgrad + k_conv_wgrad incl. split-K reduce) for the 1x1 / "
+                          "strided / stem layers, Winograd F(2x2,3x3) / F(3x3,2x2) (k_wino, k_wino_wgrad + weight transform, fix-up, reduce) for the "
+                          "thirteen 3x3 stride-1 layers — `achieved` counts the DIRECT convolution's FLOPs (SURVEY.md section 8d) for both, so the "
+                          "Winograd layers' 2.25x fewer multiplies show as rate",
                 "how": f"24.287 GFLOP/img x {B} img per step / summed HIP-event duration of the conv launches per step ({conv_ms:.2f} ms), "
                        f"events recorded on the launch stream over {psteps} instrumented steps run straight after the timed region "
                        "(serialised: no side-stream overlap, so every class's time is its own)",

@@ -14,6 +14,20 @@ from collections import defaultdict
 
 
 def klass(name):
+    # Winograd forms (round 5): the class is in the template arguments — k_wino<XF, EPI, ODD>, k_wino_fixup<EPI, ODD>, k_wino_weights<FLIP>
+    if "k_wino_wgrad" in name:
+        return "conv_wgrad"
+    if "k_wino" in name:
+        import re
+        args = re.search(r"k_wino\w*<([^>]*)>", name)
+        a = [x.strip() for x in args.group(1).split(",")] if args else []
+        if "k_wino_weights" in name:
+            epi = a[0] if a else "0"
+        elif "k_wino_fixup" in name:
+            epi = a[0] if a else "0"
+        else:
+            epi = a[1] if len(a) > 1 else "0"
+        return "conv_dgrad" if epi == "1" else "conv_fwd"
     if "k_conv_fwd" in name or "k_stem_fwd" in name or "k_conv1x1_rows" in name:
         return "conv_fwd"
     if "k_conv_dgrad" in name:
