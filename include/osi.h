@@ -55,6 +55,7 @@ const char* osi_strerror(int code);
  *   fwd_wino *       0 | 1         1        the executor runs its 3x3 stride-1 forward convolutions in the Winograd F(2x2,3x3) form (osi_conv_fwd_wino)
  *   dgrad_wino *     0 | 1         1        the same for the in-block fused 3x3 stride-1 input gradients (osi_conv_dgrad_fused_wino)
  *   wgrad_wino *     0 | 1         1        the executor's 3x3 stride-1 weight gradients in the Winograd F(3x3,2x2) form (osi_conv_wgrad_wino)
+ *   wino_wide        0 | 1         1        Winograd forward / input gradient: units of 32 tiles x 128 channels (instead of 64 x 64) where the channel count allows
  *   wino_streamk     0 | 1         1        Winograd forms: the units of the ragged last round are cut along K over all workgroups (fix-up pass); 0 = whole units
  *   bn_grid          1 .. 2^20     1024     grid cap of the BatchNorm stream kernels
  *   bn_grid_bwd      1 .. 2^20     1024     the same for the backward apply kernels

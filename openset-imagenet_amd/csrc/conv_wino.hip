@@ -258,9 +258,10 @@ __device__ __forceinline__ void epi1_apply(const WinoP& p, __amdgpu_buffer_rsrc_
 }
 
 // byte offsets of this lane's four output pixels (tile `ntile` of tile block mt, channel base of column unit nt)
+template <bool WIDE>
 __device__ __forceinline__ void out_offsets(const WinoP& p, int mt, int nt, int ntile, int wm, int hh, bool live, uint32_t (&po)[4]) {
     const int THW = p.TH * p.TW;
-    const int t = mt * 64 + ntile;
+    const int t = mt * (WIDE ? 32 : 64) + ntile;
     const int b = t / THW, rem = t - b * THW, th = rem / p.TW, tw = rem - th * p.TW;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -268,21 +269,25 @@ __device__ __forceinline__ void out_offsets(const WinoP& p, int mt, int nt, int 
         for (int j = 0; j < 2; ++j) {
             const int yy = 2 * th + i, xx = 2 * tw + j;
             const bool ok = live && t < p.T && yy < p.H && xx < p.W;
-            po[i * 2 + j] = ok ? (uint32_t)((((b * p.H + yy) * p.W + xx) * p.Nc + 64 * nt + 32 * wm + 4 * hh) * 4) : OOB;
+            po[i * 2 + j] = ok ? (uint32_t)((((b * p.H + yy) * p.W + xx) * p.Nc + (WIDE ? 128 : 64) * nt + 32 * wm + 4 * hh) * 4) : OOB;
         }
 }
 
 // XF: fused input activation. EPI: 0 forward (+ statistics when p.pmean), 1 input gradient with the in-block fused epilogue.
 // ODD: some tile slots hold pixels outside the image (odd H / W) or past the last tile — their outputs are masked out of the sums.
-template <bool XF, int EPI, bool ODD>
+// WIDE: the unit is 32 tiles x 128 channels instead of 64 x 64 — the four waves own the four 32-channel blocks of the SAME 32 tiles, so a
+// tile's patch transform (the VALU work fp32 MFMAs cannot hide) serves twice as many channels: every thread transforms a (tile, channel
+// PAIR) instead of a (tile, channel quad). For output-channel counts in 128s.
+template <bool XF, int EPI, bool ODD, bool WIDE>
 __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
-    __shared__ __attribute__((aligned(16))) float sV[2 * 16 * 64 * KC];   // 128 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    constexpr int TB = WIDE ? 32 : 64, CW = WIDE ? 128 : 64, NV = WIDE ? 2 : 4;      // tiles / channels of a unit, channels per loader thread
+    __shared__ __attribute__((aligned(16))) float sV[2 * 16 * TB * KC];   // 128 KiB (64 KiB WIDE)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = WIDE ? wave : wave >> 1, wn = WIDE ? 0 : wave & 1;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, p.y_bytes);
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(p.u, p.u_bytes);
     const int G = gridDim.x, wg = blockIdx.x;
-    const int ltile = tid >> 2, q = tid & 3;
+    const int ltile = WIDE ? tid >> 3 : tid >> 2, q = WIDE ? tid & 7 : tid & 3;      // loader: tile, channel quad (pair when WIDE)
     const int ntile = 32 * wn + (lane & 31), hh = lane >> 5;
     const int THW = p.TH * p.TW;
 
@@ -298,9 +303,9 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
     // everything that depends on the unit: loader offsets + masks, epilogue offsets, U fragment base
     auto setup = [&](int mt_, int nt_, bool live, uint32_t (&po_)[4], uint32_t& ua_) {
         {
-            const int t = mt_ * 64 + ltile;
+            const int t = mt_ * TB + ltile;
             const int b = t / THW, rem = t - b * THW, th = rem / p.TW, tw = rem - th * p.TW;
-            const uint32_t base = (uint32_t)((((b * p.H + 2 * th - 1) * p.W + 2 * tw - 1) * p.Kc + q * 4) * 4);
+            const uint32_t base = (uint32_t)((((b * p.H + 2 * th - 1) * p.W + 2 * tw - 1) * p.Kc + q * NV) * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -311,20 +316,26 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                     if constexpr (XF) okm[i * 4 + j] = __builtin_amdgcn_ballot_w64(ok);
                 }
         }
-        out_offsets(p, mt_, nt_, ntile, wm, hh, live, po_);
-        ua_ = (uint32_t)(((2 * nt_ + wm) * 2 * 64 + lane) * 16);       // + ((pos * KS + ks) * CB) * 2048 + j * 1024 bytes
+        out_offsets<WIDE>(p, mt_, nt_, ntile, wm, hh, live, po_);
+        ua_ = (uint32_t)((((CW / 32) * nt_ + wm) * 2 * 64 + lane) * 16);       // + ((pos * KS + ks) * CB) * 2048 + j * 1024 bytes
     };
     setup(mt, nt, true, po, ua);
-    float* const wbase = sV + ltile * KC + 4 * (q ^ ((ltile >> 2) & 3));              // + buf * 16384 + pos * 1024
+    // the thread's channels inside a tile's 16-channel row: 16-byte chunk (XOR-swizzled by the tile index) + offset inside the chunk
+    float* const wbase = sV + ltile * KC + (WIDE ? 4 * ((q >> 1) ^ ((ltile >> 2) & 3)) + 2 * (q & 1) : 4 * (q ^ ((ltile >> 2) & 3)));
     const float* const rb0 = sV + ntile * KC + 4 * ((0 + hh) ^ ((ntile >> 2) & 3));   // chunk of MFMAs j = 0
     const float* const rb1 = sV + ntile * KC + 4 * ((2 + hh) ^ ((ntile >> 2) & 3));   // chunk of MFMAs j = 1
     const uint32_t ustep = (uint32_t)p.CB * 2048;      // bytes per (position, slice) block of U
 
     f32x16 acc[16];
-    f32x4 xr[16];
+    f32x4 xr[16];                    // WIDE: elements 0, 1 only
     auto load_x = [&](int ks) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) xr[k] = bld4(rx, off[k], (uint32_t)ks * (KC * 4));
+        for (int k = 0; k < 16; ++k) {
+            if constexpr (WIDE) {
+                const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, off[k], (uint32_t)ks * (KC * 4), 0));
+                xr[k][0] = v[0]; xr[k][1] = v[1];
+            } else xr[k] = bld4(rx, off[k], (uint32_t)ks * (KC * 4));
+        }
     };
     // activation (+ padding select) and column transform of patch column j. asm: IR passes otherwise regroup these scalar ops (SLP packs
     // them into v_pk_*, an anti-lever beside MFMAs, and sinks the selects to their users) whatever the machine scheduler is told.
@@ -333,26 +344,40 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < NV; ++e)
                     asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_max_f32 %0, 0, %0\n\tv_cndmask_b32 %0, 0, %0, %3"
                                  : "+v"(xr[i * 4 + j][e]) : "v"(sc4[e]), "v"(sh4[e]), "s"(okm[i * 4 + j]));
         }
-        const f32x4 d0 = xr[j], d1 = xr[4 + j], d2 = xr[8 + j], d3 = xr[12 + j];
-        xr[j] = d0 - d2; xr[4 + j] = d1 + d2; xr[8 + j] = d2 - d1; xr[12 + j] = d1 - d3;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const float d0 = xr[j][e], d1 = xr[4 + j][e], d2 = xr[8 + j][e], d3 = xr[12 + j][e];
+            xr[j][e] = d0 - d2; xr[4 + j][e] = d1 + d2; xr[8 + j][e] = d2 - d1; xr[12 + j][e] = d1 - d3;
+        }
     };
     // row transform of patch row i and its four LDS stores
     auto row_store = [&](int i, int buf) {
-        const f32x4 t0 = xr[i * 4], t1 = xr[i * 4 + 1], t2 = xr[i * 4 + 2], t3 = xr[i * 4 + 3];
-        float* w = wbase + buf * (16 * 64 * KC) + (i * 4) * (64 * KC);
-        *reinterpret_cast<f32x4*>(w) = t0 - t2;
-        *reinterpret_cast<f32x4*>(w + 64 * KC) = t1 + t2;
-        *reinterpret_cast<f32x4*>(w + 2 * 64 * KC) = t2 - t1;
-        *reinterpret_cast<f32x4*>(w + 3 * 64 * KC) = t1 - t3;
+        float* w = wbase + buf * (16 * TB * KC) + (i * 4) * (TB * KC);
+        f32x4 o[4];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const float t0 = xr[i * 4][e], t1 = xr[i * 4 + 1][e], t2 = xr[i * 4 + 2][e], t3 = xr[i * 4 + 3][e];
+            o[0][e] = t0 - t2; o[1][e] = t1 + t2; o[2][e] = t2 - t1; o[3][e] = t1 - t3;
+        }
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            if constexpr (WIDE) *reinterpret_cast<f32x2*>(w + nu * (TB * KC)) = f32x2{o[nu][0], o[nu][1]};
+            else *reinterpret_cast<f32x4*>(w + nu * (TB * KC)) = o[nu];
+        }
     };
     auto ld_scale = [&](int ks, f32x4& sc4, f32x4& sh4) {
         if constexpr (XF) {
-            sc4 = ld4(p.sc + ks * KC + 4 * q);
-            sh4 = ld4(p.sh + ks * KC + 4 * q);
+            if constexpr (WIDE) {
+                const f32x2 a = *reinterpret_cast<const f32x2*>(p.sc + ks * KC + 2 * q), b = *reinterpret_cast<const f32x2*>(p.sh + ks * KC + 2 * q);
+                sc4[0] = a[0]; sc4[1] = a[1]; sh4[0] = b[0]; sh4[1] = b[1];
+            } else {
+                sc4 = ld4(p.sc + ks * KC + 4 * q);
+                sh4 = ld4(p.sh + ks * KC + 4 * q);
+            }
         }
     };
 
@@ -397,8 +422,8 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
             }
             load_x(ksn);
             ld_scale(ksn, sc4, sh4);
-            const float* r0 = rb0 + buf * (16 * 64 * KC);
-            const float* r1 = rb1 + buf * (16 * 64 * KC);
+            const float* r0 = rb0 + buf * (16 * TB * KC);
+            const float* r1 = rb1 + buf * (16 * TB * KC);
             f32x4 b0 = *reinterpret_cast<const f32x4*>(r0), b1 = *reinterpret_cast<const f32x4*>(r1);
             __builtin_amdgcn_sched_barrier(0);
             auto position = [&](auto POSC) {
@@ -407,8 +432,8 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                 else load_u(pos + PF - 16, uan, ksn);
                 f32x4 nb0 = b0, nb1 = b1;
                 if (pos < 15) {
-                    nb0 = *reinterpret_cast<const f32x4*>(r0 + (pos + 1) * (64 * KC));
-                    nb1 = *reinterpret_cast<const f32x4*>(r1 + (pos + 1) * (64 * KC));
+                    nb0 = *reinterpret_cast<const f32x4*>(r0 + (pos + 1) * (TB * KC));
+                    nb1 = *reinterpret_cast<const f32x4*>(r1 + (pos + 1) * (TB * KC));
                 }
                 const f32x4 a0 = a[pos][0], a1 = a[pos][1];
 #pragma unroll
@@ -426,8 +451,8 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
         }
 
         // ---- epilogue: Y = A^T M A per (tile, channel); per lane 4 pixels x 4 quads of 4 consecutive channels ------------------------
-        const int ch0 = 64 * cur_nt + 32 * wm + 4 * hh;                                  // + 8 g: first channel of quad g
-        const int part = cur_mt * 4 + 2 * wn + ((lane >> 4) & 1);                        // this lane's 16-tile statistics group
+        const int ch0 = CW * cur_nt + 32 * wm + 4 * hh;                                  // + 8 g: first channel of quad g
+        const int part = cur_mt * (TB / 16) + 2 * wn + ((lane >> 4) & 1);                // this lane's 16-tile statistics group
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.slab, p.slab_bytes);
         const __amdgpu_buffer_rsrc_t r0y = make_rsrc(EPI == 1 ? p.ey0 : p.y, p.y_bytes);
         Epi1Ops L1{};
@@ -475,15 +500,15 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
 // One WAVE per (remainder unit, wave role, channel quad) — 16 single-wave workgroups per unit, so that a small remainder still fills the
 // chip: adds the unit's pieces (slab slots of the workgroups whose slice ranges meet it, in workgroup order) and runs the ordinary
 // epilogue of that quad with k_wino's own lane roles (the statistics / sums are per DPP row of 16 lanes: a wave is self-contained).
-template <int EPI, bool ODD>
+template <int EPI, bool ODD, bool WIDE>
 __global__ __launch_bounds__(64) void k_wino_fixup(WinoP p, int G) {
     const int lane = threadIdx.x, u = blockIdx.x >> 4, wave = (blockIdx.x >> 2) & 3, g = blockIdx.x & 3;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WIDE ? wave : wave >> 1, wn = WIDE ? 0 : wave & 1;
     const int ntile = 32 * wn + (lane & 31), hh = lane >> 5;
     int mt, nt;
     unit_of(p.q * G + u, p.MT, p.NT, mt, nt);
     uint32_t po[4];
-    out_offsets(p, mt, nt, ntile, wm, hh, true, po);
+    out_offsets<WIDE>(p, mt, nt, ntile, wm, hh, true, po);
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, p.y_bytes);
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.slab, p.slab_bytes);
     const int s0 = u * p.KS, s1 = s0 + p.KS;
@@ -502,7 +527,7 @@ __global__ __launch_bounds__(64) void k_wino_fixup(WinoP p, int G) {
         }
         b0 = b1;
     }
-    const int ch0 = 64 * nt + 32 * wm + 4 * hh, part = mt * 4 + 2 * wn + ((lane >> 4) & 1);
+    const int ch0 = (WIDE ? 128 : 64) * nt + 32 * wm + 4 * hh, part = mt * (WIDE ? 2 : 4) + 2 * wn + ((lane >> 4) & 1);
     if constexpr (EPI == 0) epi0_quad<ODD>(p, ry, g, o, po, ch0, part, lane);
     else {
         const Epi1Ops L = epi1_load(p, make_rsrc(p.ey0, p.y_bytes), g, po, ch0);
@@ -811,9 +836,14 @@ int launch_weights(const float* w, float* u, int Kc, int Nc, hipStream_t st) {
     return OSI_OK;
 }
 
+// the 32-tile x 128-channel unit wherever the output-channel count allows (knob wino_wide)
+bool wide_units(int Nc) { return g_osi_tuning.wino_wide && Nc % 128 == 0; }
+
 WinoP make_wp(const osi_conv_desc* d, const Geo& g, int Kc, int Nc) {
     WinoP p{};
-    p.H = d->H; p.W = d->W; p.Kc = Kc; p.Nc = Nc; p.TH = g.TH; p.TW = g.TW; p.T = g.T; p.KS = Kc / KC; p.CB = Nc / 32; p.MT = g.MT; p.NT = Nc / 64;
+    const bool wide = wide_units(Nc);
+    p.H = d->H; p.W = d->W; p.Kc = Kc; p.Nc = Nc; p.TH = g.TH; p.TW = g.TW; p.T = g.T; p.KS = Kc / KC; p.CB = Nc / 32;
+    p.MT = wide ? (g.T + 31) / 32 : g.MT; p.NT = Nc / (wide ? 128 : 64);
     p.x_bytes = (int)((size_t)d->B * d->H * d->W * Kc * 4);
     p.y_bytes = (int)((size_t)d->B * d->H * d->W * Nc * 4);
     p.u_bytes = (int)((size_t)16 * Kc * Nc * 4);
@@ -885,20 +915,29 @@ int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_sc
     const int G = wino_grid();
     plan_units(p, ws, d, G);
     const dim3 grid((unsigned)G), blk(256);
-    if (in_scale) {
-        if (g.odd) hipLaunchKernelGGL((k_wino<true, 0, true>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((k_wino<true, 0, false>), grid, blk, 0, st, p);
-    } else {
-        if (g.odd) hipLaunchKernelGGL((k_wino<false, 0, true>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((k_wino<false, 0, false>), grid, blk, 0, st, p);
+    const bool wide = wide_units(d->Cout), odd = g.odd || (wide && g.T % 32 != 0);
+    auto launch = [&](auto XFC, auto ODDC, auto WIDEC) {
+        constexpr bool xf = decltype(XFC)::value, od = decltype(ODDC)::value, wd = decltype(WIDEC)::value;
+        hipLaunchKernelGGL((k_wino<xf, 0, od, wd>), grid, blk, 0, st, p);
+        if (hipGetLastError() != hipSuccess) return OSI_ERR_LAUNCH;
+        if (p.r > 0) {
+            hipLaunchKernelGGL((k_wino_fixup<0, od, wd>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
+            if (hipGetLastError() != hipSuccess) return OSI_ERR_LAUNCH;
+        }
+        return OSI_OK;
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    const int sel = (in_scale ? 4 : 0) | (odd ? 2 : 0) | (wide ? 1 : 0);
+    switch (sel) {
+        case 0: return launch(F_{}, F_{}, F_{});
+        case 1: return launch(F_{}, F_{}, T_{});
+        case 2: return launch(F_{}, T_{}, F_{});
+        case 3: return launch(F_{}, T_{}, T_{});
+        case 4: return launch(T_{}, F_{}, F_{});
+        case 5: return launch(T_{}, F_{}, T_{});
+        case 6: return launch(T_{}, T_{}, F_{});
+        default: return launch(T_{}, T_{}, T_{});
     }
-    OSI_LAUNCH_CHECK();
-    if (p.r > 0) {
-        if (g.odd) hipLaunchKernelGGL((k_wino_fixup<0, true>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
-        else hipLaunchKernelGGL((k_wino_fixup<0, false>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
-        OSI_LAUNCH_CHECK();
-    }
-    return OSI_OK;
 }
 
 /* Winograd twin of osi_conv_dgrad_fused for the executor's "in-block" fusion only: no addend, no stored bitmask, one consumer, no pool
@@ -926,15 +965,20 @@ int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const flo
     const int G = wino_grid();
     plan_units(p, ws, d, G);
     const dim3 grid((unsigned)G), blk(256);
-    if (g.odd) hipLaunchKernelGGL((k_wino<false, 1, true>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((k_wino<false, 1, false>), grid, blk, 0, st, p);
-    OSI_LAUNCH_CHECK();
-    if (p.r > 0) {
-        if (g.odd) hipLaunchKernelGGL((k_wino_fixup<1, true>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
-        else hipLaunchKernelGGL((k_wino_fixup<1, false>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
-        OSI_LAUNCH_CHECK();
-    }
-    return OSI_OK;
+    const bool wide = wide_units(d->Cin), odd = g.odd || (wide && g.T % 32 != 0);
+    auto launch = [&](auto ODDC, auto WIDEC) {
+        constexpr bool od = decltype(ODDC)::value, wd = decltype(WIDEC)::value;
+        hipLaunchKernelGGL((k_wino<false, 1, od, wd>), grid, blk, 0, st, p);
+        if (hipGetLastError() != hipSuccess) return OSI_ERR_LAUNCH;
+        if (p.r > 0) {
+            hipLaunchKernelGGL((k_wino_fixup<1, od, wd>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
+            if (hipGetLastError() != hipSuccess) return OSI_ERR_LAUNCH;
+        }
+        return OSI_OK;
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    if (odd) return wide ? launch(T_{}, T_{}) : launch(T_{}, F_{});
+    return wide ? launch(F_{}, T_{}) : launch(F_{}, F_{});
 }
 
 /* Winograd F(3x3, 2x2) twin of osi_conv_wgrad / osi_conv_wgrad_act (in_scale / in_shift NULL: plain input) for 3x3 / stride 1 / pad 1

@@ -159,7 +159,7 @@ def lib():
         _lib = handle
         # development A/B switches: the environment is read HERE, once, and handed to the library explicitly
         for env, knob in (("OSI_WGRAD_TILE", b"wgrad_tile"), ("OSI_WGRAD_BLOCKS", b"wgrad_blocks"), ("OSI_WGRAD_NST", b"wgrad_nst"),
-                          ("OSI_WGRAD_GROUP", b"wgrad_group"), ("OSI_BN_GRID", b"bn_grid"), ("OSI_BN_GRID_BWD", b"bn_grid_bwd"), ("OSI_BN_SINGLE_P", b"bn_single_p"), ("OSI_BN_WIDE_P", b"bn_wide_p"), ("OSI_TAIL_GAIN", b"tail_gain"), ("OSI_TAIL_QMAX", b"tail_qmax"), ("OSI_WGRAD3", b"wgrad3"), ("OSI_WGRAD3_BLOCKS", b"wgrad3_blocks"), ("OSI_FWD_WIDE", b"fwd_wide"), ("OSI_DGRAD_WIDE", b"dgrad_wide"), ("OSI_TAIL_SPLIT", b"tail_split"), ("OSI_TAIL_CUS", b"tail_cus"), ("OSI_TAIL_SMAX", b"tail_smax"), ("OSI_TAIL_MINT", b"tail_mint"), ("OSI_STEM_DIRECT", b"stem_direct"), ("OSI_DP_RESERVED_CUS", b"dp_reserved_cus"), ("OSI_FWD_ROWS", b"fwd_rows"), ("OSI_FWD_W3", b"fwd_w3"), ("OSI_DGRAD_W3", b"dgrad_w3"), ("OSI_FWD_WINO", b"fwd_wino"), ("OSI_DGRAD_WINO", b"dgrad_wino"), ("OSI_WINO_STREAMK", b"wino_streamk"), ("OSI_WGRAD_WINO", b"wgrad_wino")):
+                          ("OSI_WGRAD_GROUP", b"wgrad_group"), ("OSI_BN_GRID", b"bn_grid"), ("OSI_BN_GRID_BWD", b"bn_grid_bwd"), ("OSI_BN_SINGLE_P", b"bn_single_p"), ("OSI_BN_WIDE_P", b"bn_wide_p"), ("OSI_TAIL_GAIN", b"tail_gain"), ("OSI_TAIL_QMAX", b"tail_qmax"), ("OSI_WGRAD3", b"wgrad3"), ("OSI_WGRAD3_BLOCKS", b"wgrad3_blocks"), ("OSI_FWD_WIDE", b"fwd_wide"), ("OSI_DGRAD_WIDE", b"dgrad_wide"), ("OSI_TAIL_SPLIT", b"tail_split"), ("OSI_TAIL_CUS", b"tail_cus"), ("OSI_TAIL_SMAX", b"tail_smax"), ("OSI_TAIL_MINT", b"tail_mint"), ("OSI_STEM_DIRECT", b"stem_direct"), ("OSI_DP_RESERVED_CUS", b"dp_reserved_cus"), ("OSI_FWD_ROWS", b"fwd_rows"), ("OSI_FWD_W3", b"fwd_w3"), ("OSI_DGRAD_W3", b"dgrad_w3"), ("OSI_FWD_WINO", b"fwd_wino"), ("OSI_DGRAD_WINO", b"dgrad_wino"), ("OSI_WINO_STREAMK", b"wino_streamk"), ("OSI_WGRAD_WINO", b"wgrad_wino"), ("OSI_WINO_WIDE", b"wino_wide")):
             if os.environ.get(env):
                 check(handle.osi_set_tuning(knob, int(os.environ[env])), f"osi_set_tuning({knob.decode()})")
     return _lib

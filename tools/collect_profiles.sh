@@ -8,13 +8,22 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/${1:-prof_final}
 mkdir -p "$OUT"
 echo "${OSI_COMMIT:-unknown}" > "$OUT/commit.txt"
-python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
+note() { echo "$(date +%T) $*" >> "$OUT/progress.log"; }   # a line per stage: the run is never silent for minutes
+note start
+python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --sustained-steps 0 > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
+note "plain bench done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --sustained-steps 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+note "kernel stats done"
 # the same with the weight gradients kept on the main stream (no co-running kernels): per-kernel averages comparable with the
 # event-timed per-class figures of bench.py's roofline leg
-OSI_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d "$OUT/stats_serial" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof_serial.json" 2> "$OUT/stats_serial.err"
+OSI_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d "$OUT/stats_serial" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --sustained-steps 0 > "$OUT/bench_under_rocprof_serial.json" 2> "$OUT/stats_serial.err"
+note "serialized kernel stats done"
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
-  rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_$c.json" 2> "$OUT/$c.err"
+  note "pmc $c"
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --sustained-steps 0 > "$OUT/bench_$c.json" 2> "$OUT/$c.err"
 done
+# keep what tools/summarize_profiles.py reads; the per-dispatch traces of the stats runs are large
+find "$OUT" -name "*_kernel_trace.csv" -path "*stats*" -delete 2>/dev/null || true
+note done
 echo done
