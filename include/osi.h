@@ -117,6 +117,16 @@ int osi_conv_fwd_act2(const osi_conv_desc* d, const float* x, const float* in_sc
  * recomputed), no addend / relu_mask / y1 / pool mode; f->partials optional ([3][*P][Cin], planes 0 and 1 written). */
 int osi_conv_wino_eligible(const osi_conv_desc* d, int input_gradient);
 size_t osi_conv_wino_workspace(const osi_conv_desc* d);
+/* The transformed weights of a convolution can be built AHEAD of its launches (they are the same for the forward and the backward pass of a
+ * step): osi_conv_wino_transform_weights writes them into `u` (osi_conv_wino_weights_bytes(d) bytes; input_gradient = 1: the flipped /
+ * transposed form of the input gradient), and the `_pre` calls take `u` instead of the raw weights plus the shared stream-K slab
+ * (osi_conv_wino_slab_bytes() bytes, the same for every convolution). The executor does this for all its 3x3 layers on the side stream at
+ * the start of a forward pass. */
+size_t osi_conv_wino_weights_bytes(const osi_conv_desc* d);
+size_t osi_conv_wino_slab_bytes(void);
+int osi_conv_wino_transform_weights(const osi_conv_desc* d, const float* w, int input_gradient, float* u, size_t u_bytes, osi_stream_t stream);
+int osi_conv_fwd_wino_pre(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* u, float* y,
+                          void* slab, size_t slab_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
 int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
                       void* ws, size_t ws_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
 /* dx (+)= conv2d_input_grad(dy, w). accumulate = 1 adds into dx (skip-connection sum); accumulate = 2 ("sparse", ABI 4) writes
@@ -159,6 +169,8 @@ int osi_conv_dgrad_fused(const osi_conv_desc* d, const float* dy, const float* w
                          const osi_dgrad_fusion* f, int tile, int* P, osi_stream_t stream);
 int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const osi_dgrad_fusion* f, void* ws,
                               size_t ws_bytes, int* P, osi_stream_t stream);
+int osi_conv_dgrad_fused_wino_pre(const osi_conv_desc* d, const float* dy, const float* u, float* dx, const osi_dgrad_fusion* f, void* slab,
+                                  size_t slab_bytes, int* P, osi_stream_t stream);
 /* dw = conv2d_weight_grad(dy, x), deterministic split-K through `ws` (size from osi_conv_wgrad_workspace). The stem writes
  * the packed [Cout][224] form; osi_stem_grad_unpack converts to [Cout][7][7][3]. */
 size_t osi_conv_wgrad_workspace(const osi_conv_desc* d);

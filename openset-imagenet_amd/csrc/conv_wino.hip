@@ -861,7 +861,7 @@ size_t u_bytes_of(const osi_conv_desc* d) { return ((size_t)16 * d->Cin * d->Cou
 size_t slab_bytes_of() { return (size_t)(hw_cus() / 8 * 8 < 8 ? 8 : hw_cus() / 8 * 8) * 2 * SLOT_BYTES; }
 
 // q full rounds + r remainder units over G workgroups; slab behind the transformed weights
-void plan_units(WinoP& p, void* ws, const osi_conv_desc* d, int G) {
+void plan_units(WinoP& p, void* slab, const osi_conv_desc* d, int G) {
     const int V = p.MT * p.NT;
     p.q = V / G; p.r = V - p.q * G; p.nfull = p.q * G;
     // short units (KS <= 4: the 64-channel layers) keep their ragged last round: a piece of one or two slices plus the fix-up pass costs
@@ -869,7 +869,7 @@ void plan_units(WinoP& p, void* ws, const osi_conv_desc* d, int G) {
     // — unless the ragged round is a large part of a short launch (small batches: B = 64 leaves 16 units for a 4th round of 3.06)
     const bool heavy_tail = p.r > 0 && (double)(G - p.r) / (double)G / (double)(p.q + 1) >= 0.15;
     if (!g_osi_tuning.wino_streamk || (p.KS <= 4 && !heavy_tail)) { p.nfull = V; p.r = 0; }
-    p.slab = (float*)((char*)ws + u_bytes_of(d));
+    p.slab = (float*)slab;
     p.slab_bytes = (int)((size_t)G * 2 * SLOT_BYTES);
 }
 
@@ -896,24 +896,26 @@ size_t osi_conv_wino_workspace(const osi_conv_desc* d) {
 
 /* Winograd twin of osi_conv_fwd_act / osi_conv_fwd_bnstats: in_scale / in_shift may be NULL (plain input). P = ceil(tiles / 16),
  * rows_per_block = valid pixels of a 16-tile group (64 for even H, W). pstats needs 2 * P * Cout floats. */
-int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
-                      void* ws, size_t ws_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream) {
-    OSI_REQUIRE(x && w && y && ws && osi_conv_wino_eligible(d, 0));
+// w != NULL: transformed into `u` first; w == NULL: `u` already holds this convolution's transformed weights (osi_conv_wino_transform_weights)
+static int fwd_wino_impl(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* u,
+                         float* y, void* slab, size_t slab_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block,
+                         osi_stream_t stream) {
+    OSI_REQUIRE(x && u && y && slab && osi_conv_wino_eligible(d, 0));
     OSI_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
-    OSI_REQUIRE(ws_bytes >= osi_conv_wino_workspace(d));
+    OSI_REQUIRE(slab_bytes >= slab_bytes_of());
     OSI_REQUIRE(!pstats || (P && rows_per_block));
     hipStream_t st = (hipStream_t)stream;
     const Geo g = geo_of(d);
     WinoP p = make_wp(d, g, d->Cin, d->Cout);
-    p.x = x; p.u = (const float*)ws; p.y = y; p.sc = in_scale; p.sh = in_shift;
+    p.x = x; p.u = u; p.y = y; p.sc = in_scale; p.sh = in_shift;
     if (pstats) {
         OSI_REQUIRE(pstats_bytes >= (size_t)2 * g.P * d->Cout * sizeof(float));
         p.pmean = pstats; p.pm2 = pstats + (size_t)g.P * d->Cout;
         *P = g.P; *rows_per_block = (int)g.cnt;
     }
-    if (int e = launch_weights<0>(w, (float*)ws, d->Cin, d->Cout, st)) return e;
+    if (w) { if (int e = launch_weights<0>(w, u, d->Cin, d->Cout, st)) return e; }
     const int G = wino_grid();
-    plan_units(p, ws, d, G);
+    plan_units(p, slab, d, G);
     const dim3 grid((unsigned)G), blk(256);
     const bool wide = wide_units(d->Cout), odd = g.odd || (wide && g.T % 32 != 0);
     auto launch = [&](auto XFC, auto ODDC, auto WIDEC) {
@@ -940,19 +942,42 @@ int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_sc
     }
 }
 
+int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
+                      void* ws, size_t ws_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream) {
+    OSI_REQUIRE(w && ws && wino_shape(d) && ws_bytes >= osi_conv_wino_workspace(d));
+    return fwd_wino_impl(d, x, in_scale, in_shift, w, (float*)ws, y, (char*)ws + u_bytes_of(d), ws_bytes - u_bytes_of(d), pstats, pstats_bytes, P,
+                         rows_per_block, stream);
+}
+
+/* The weights of one convolution transformed ahead of its launches (they are the same for the forward and the backward pass of a step,
+ * and for every forward until the optimizer runs): u = osi_conv_wino_weights_bytes(d) bytes, input_gradient selects the flipped /
+ * transposed form osi_conv_dgrad_fused_wino_pre reads. The `_pre` calls take such a buffer instead of the raw weights, plus the shared
+ * stream-K slab (osi_conv_wino_slab_bytes() bytes, any convolution). The executor transforms all its 3x3 layers on the side stream at the
+ * start of a forward pass, off the critical path. */
+size_t osi_conv_wino_weights_bytes(const osi_conv_desc* d) { return wino_shape(d) ? u_bytes_of(d) : 0; }
+size_t osi_conv_wino_slab_bytes(void) { return slab_bytes_of(); }
+int osi_conv_wino_transform_weights(const osi_conv_desc* d, const float* w, int input_gradient, float* u, size_t u_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(w && u && osi_conv_wino_eligible(d, input_gradient ? 1 : 0) && u_bytes >= u_bytes_of(d));
+    return input_gradient ? launch_weights<1>(w, u, d->Cout, d->Cin, (hipStream_t)stream) : launch_weights<0>(w, u, d->Cin, d->Cout, (hipStream_t)stream);
+}
+int osi_conv_fwd_wino_pre(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* u, float* y,
+                          void* slab, size_t slab_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream) {
+    return fwd_wino_impl(d, x, in_scale, in_shift, nullptr, const_cast<float*>(u), y, slab, slab_bytes, pstats, pstats_bytes, P, rows_per_block, stream);
+}
+
 /* Winograd twin of osi_conv_dgrad_fused for the executor's "in-block" fusion only: no addend, no stored bitmask, one consumer, no pool
  * mode; gate recomputed from f->y0 (scale0 / shift0 required), partial sums optional. P = ceil(tiles / 16) groups of <= 64 pixels. */
-int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const osi_dgrad_fusion* f, void* ws,
-                              size_t ws_bytes, int* P, osi_stream_t stream) {
-    OSI_REQUIRE(dy && w && dx && ws && f && P && osi_conv_wino_eligible(d, 1));
+static int dgrad_wino_impl(const osi_conv_desc* d, const float* dy, const float* w, float* u, float* dx, const osi_dgrad_fusion* f, void* slab,
+                           size_t slab_bytes, int* P, osi_stream_t stream) {
+    OSI_REQUIRE(dy && u && dx && slab && f && P && osi_conv_wino_eligible(d, 1));
     OSI_REQUIRE(!f->relu_mask && !f->y1 && !f->pool_idx && f->addend_stride != 2);
     OSI_REQUIRE(f->y0 && f->scale0 && f->shift0);
     OSI_REQUIRE(!f->partials || (f->mean0 && f->invstd0));
-    OSI_REQUIRE(ws_bytes >= osi_conv_wino_workspace(d));
+    OSI_REQUIRE(slab_bytes >= slab_bytes_of());
     hipStream_t st = (hipStream_t)stream;
     const Geo g = geo_of(d);
     WinoP p = make_wp(d, g, d->Cout, d->Cin);
-    p.x = dy; p.u = (const float*)ws; p.y = dx;
+    p.x = dy; p.u = u; p.y = dx;
     p.ey0 = f->y0; p.escale0 = f->scale0; p.eshift0 = f->shift0;
     // without partial sums the epilogue still evaluates xhat: any readable per-channel vectors do
     p.emean0 = f->mean0 ? f->mean0 : f->scale0; p.einv0 = f->invstd0 ? f->invstd0 : f->scale0;
@@ -961,9 +986,9 @@ int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const flo
         p.esum = f->partials;
     }
     *P = g.P;
-    if (int e = launch_weights<1>(w, (float*)ws, d->Cout, d->Cin, st)) return e;
+    if (w) { if (int e = launch_weights<1>(w, u, d->Cout, d->Cin, st)) return e; }
     const int G = wino_grid();
-    plan_units(p, ws, d, G);
+    plan_units(p, slab, d, G);
     const dim3 grid((unsigned)G), blk(256);
     const bool wide = wide_units(d->Cin), odd = g.odd || (wide && g.T % 32 != 0);
     auto launch = [&](auto ODDC, auto WIDEC) {
@@ -979,6 +1004,16 @@ int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const flo
     using T_ = std::true_type; using F_ = std::false_type;
     if (odd) return wide ? launch(T_{}, T_{}) : launch(T_{}, F_{});
     return wide ? launch(F_{}, T_{}) : launch(F_{}, F_{});
+}
+
+int osi_conv_dgrad_fused_wino(const osi_conv_desc* d, const float* dy, const float* w, float* dx, const osi_dgrad_fusion* f, void* ws,
+                              size_t ws_bytes, int* P, osi_stream_t stream) {
+    OSI_REQUIRE(w && ws && wino_shape(d) && ws_bytes >= osi_conv_wino_workspace(d));
+    return dgrad_wino_impl(d, dy, w, (float*)ws, dx, f, (char*)ws + u_bytes_of(d), ws_bytes - u_bytes_of(d), P, stream);
+}
+int osi_conv_dgrad_fused_wino_pre(const osi_conv_desc* d, const float* dy, const float* u, float* dx, const osi_dgrad_fusion* f, void* slab,
+                                  size_t slab_bytes, int* P, osi_stream_t stream) {
+    return dgrad_wino_impl(d, dy, nullptr, const_cast<float*>(u), dx, f, slab, slab_bytes, P, stream);
 }
 
 /* Winograd F(3x3, 2x2) twin of osi_conv_wgrad / osi_conv_wgrad_act (in_scale / in_shift NULL: plain input) for 3x3 / stride 1 / pad 1

@@ -40,6 +40,7 @@ struct Conv {
     size_t y;      // workspace: conv output (pre-BN)
     size_t a;      // workspace: BN(+res)+ReLU output (SIZE_MAX for downsample: goes to scratch)
     size_t mask;   // workspace: ReLU bitmask of `a` (1 bit per element)
+    size_t u_fw = (size_t)-1, u_bw = (size_t)-1;   // workspace: Winograd-transformed weights (forward / input-gradient form), 3x3 stride-1 layers only
 };
 struct Block {
     int c1, c2, c3, ds;  // conv indices, ds = -1 if identity skip
@@ -199,7 +200,9 @@ struct osi_resnet50 {
                a.dp_reserved_cus == b.dp_reserved_cus && a.fwd_wino == b.fwd_wino && a.dgrad_wino == b.dgrad_wino && a.wgrad_wino == b.wgrad_wino;
     }
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wdone = nullptr, ev_rmain = nullptr, ev_rside = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wdone = nullptr, ev_rmain = nullptr, ev_rside = nullptr, ev_wt = nullptr;
+    bool wt_aside = true;            // option "wino_weights_aside": the Winograd weight transforms of a training forward run on the side stream (A/B: 0 = main)
+    bool wt_pending = false;         // the Winograd weight transforms of this forward run on the side stream: the first consumer waits for ev_wt
     hipEvent_t buf_ev[NSCR] = {};
     bool buf_pending[NSCR] = {};
     bool side_dirty = false;
@@ -212,6 +215,7 @@ struct osi_resnet50 {
         if (hipEventCreateWithFlags(&ev_fork, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
         if (hipEventCreateWithFlags(&ev_join, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
         if (hipEventCreateWithFlags(&ev_wdone, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
+        if (hipEventCreateWithFlags(&ev_wt, EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
         for (int i = 0; i < NSCR; ++i)
             if (hipEventCreateWithFlags(&buf_ev[i], EV_FLAGS) != hipSuccess) return OSI_ERR_LAUNCH;
         return OSI_OK;
@@ -242,7 +246,7 @@ struct osi_resnet50 {
         for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
         if (side) {
             (void)hipStreamSynchronize(side);
-            (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_wdone);
+            (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_wdone); (void)hipEventDestroy(ev_wt);
             for (int i = 0; i < NSCR; ++i) (void)hipEventDestroy(buf_ev[i]);
             (void)hipStreamDestroy(side);
         }
@@ -325,9 +329,12 @@ int osi_resnet50_create(osi_resnet50_t* out, int B, int H, int W, int fc_dim, in
         if (wg > wgws) wgws = wg;
         if (!(c.d.Cin == 4 && c.d.R == 7)) { size_t dg = osi_conv_dgrad_fused_workspace(&c.d); if (dg > dgws) dgws = dg; }
         if (osi_conv_wino_eligible(&c.d, 0) || osi_conv_wino_eligible(&c.d, 1)) {
-            // Winograd forms: one (mean, M2) / (sum g, sum g xhat) partial per 16 tiles (+ the merge scratch behind the statistics)
+            // Winograd forms: one (mean, M2) / (sum g, sum g xhat) partial per 16 tiles (+ the merge scratch behind the statistics); the
+            // transformed weights of both directions live per layer (built on the side stream at the start of a forward pass)
             const size_t Pw = ((size_t)c.d.B * ((c.d.H + 1) / 2) * ((c.d.W + 1) / 2) + 15) / 16;
-            size_t w = osi_conv_wino_workspace(&c.d);
+            if (osi_conv_wino_eligible(&c.d, 0)) c.u_fw = n->ws_alloc(osi_conv_wino_weights_bytes(&c.d) / sizeof(float));
+            if (osi_conv_wino_eligible(&c.d, 1)) c.u_bw = n->ws_alloc(osi_conv_wino_weights_bytes(&c.d) / sizeof(float));
+            size_t w = osi_conv_wino_slab_bytes();
             if (w > winows) winows = w;
             w = (2 * Pw + 64) * c.d.Cout * sizeof(float);
             if (w > bnws) bnws = w;
@@ -445,12 +452,16 @@ static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buff
     const float* isc = in_bn >= 0 ? ws + n->bns[in_bn].scale : nullptr;
     const float* ish = in_bn >= 0 ? ws + n->bns[in_bn].shift : nullptr;
     // 3x3 / stride 1 (conv2 of a bottleneck without a stride): Winograd F(2x2,3x3), 2.25x fewer multiplies (csrc/conv_wino.hip); main stream only
-    const bool wino = n->plan_knobs.fwd_wino && isc && !in_res && (n->side == nullptr || st != n->side) && osi_conv_wino_eligible(&c.d, 0);
+    const bool wino = n->plan_knobs.fwd_wino && isc && !in_res && (n->side == nullptr || st != n->side) && c.u_fw != (size_t)-1;
+    if (wino && n->wt_pending) {      // the transformed weights come from the side stream
+        if (hipStreamWaitEvent(st, n->ev_wt, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+        n->wt_pending = false;
+    }
     if (training) {
         // batch statistics come out of the conv epilogue (per row tile), only a tiny per-channel merge follows
         int P = 0, rows = 0;
         if (isc && in_res) OSI_TRY(osi_conv_fwd_act2(&c.d, x, isc, ish, in_res, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
-        else if (isc && wino) OSI_TRY(osi_conv_fwd_wino(&c.d, x, isc, ish, w, ws + c.y, ws + n->wino_ws, n->wino_ws_bytes, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
+        else if (isc && wino) OSI_TRY(osi_conv_fwd_wino_pre(&c.d, x, isc, ish, ws + c.u_fw, ws + c.y, ws + n->wino_ws, n->wino_ws_bytes, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
         else if (isc) OSI_TRY(osi_conv_fwd_act(&c.d, x, isc, ish, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
         else OSI_TRY(osi_conv_fwd_bnstats(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, ws + bn_ws_off, n->bn_ws_bytes, &P, &rows, st));
         OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
@@ -459,7 +470,7 @@ static int conv_bn_fwd(osi_resnet50* n, int ci, const float* params, float* buff
                                       ws + b.shift, st));
     } else {
         if (isc && in_res) OSI_TRY(osi_conv_fwd_act2(&c.d, x, isc, ish, in_res, w, ws + c.y, OSI_TILE_AUTO, nullptr, 0, nullptr, nullptr, st));
-        else if (isc && wino) OSI_TRY(osi_conv_fwd_wino(&c.d, x, isc, ish, w, ws + c.y, ws + n->wino_ws, n->wino_ws_bytes, nullptr, 0, nullptr, nullptr, st));
+        else if (isc && wino) OSI_TRY(osi_conv_fwd_wino_pre(&c.d, x, isc, ish, ws + c.u_fw, ws + c.y, ws + n->wino_ws, n->wino_ws_bytes, nullptr, 0, nullptr, nullptr, st));
         else if (isc) OSI_TRY(osi_conv_fwd_act(&c.d, x, isc, ish, w, ws + c.y, OSI_TILE_AUTO, nullptr, 0, nullptr, nullptr, st));
         else OSI_TRY(osi_conv_fwd(&c.d, x, w, ws + c.y, OSI_TILE_AUTO, st));
         OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
@@ -502,6 +513,31 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     n->fwd_done = false;
     if (training && n->overlap && (!n->prof_on || n->prof_timeline)) OSI_TRY(n->ensure_side());
     OSI_TRY(n->mark(OSI_PROF_START, st));
+    // Winograd weight transforms of every 3x3 stride-1 layer, both directions: the weights are the same for this forward and its backward.
+    // On the side stream beside the stem (26 launches of 4 - 16 us that used to sit in front of their convolutions); the first Winograd
+    // convolution waits for them.
+    if (n->plan_knobs.fwd_wino || (training && n->plan_knobs.dgrad_wino)) {
+        const bool aside = n->async_wgrad() && n->wt_aside;
+        hipStream_t wt = aside ? n->side : st;
+        if (aside) {
+            if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
+            if (hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+        }
+        for (auto& c : n->convs)
+            if (n->plan_knobs.fwd_wino && c.u_fw != (size_t)-1)
+                OSI_TRY(osi_conv_wino_transform_weights(&c.d, params + c.w_off, 0, ws + c.u_fw, osi_conv_wino_weights_bytes(&c.d), wt));
+        OSI_TRY(n->mark(OSI_PROF_CONV_FWD, wt));
+        if (training && n->plan_knobs.dgrad_wino) {
+            for (auto& c : n->convs)
+                if (c.u_bw != (size_t)-1)
+                    OSI_TRY(osi_conv_wino_transform_weights(&c.d, params + c.w_off, 1, ws + c.u_bw, osi_conv_wino_weights_bytes(&c.d), wt));
+            OSI_TRY(n->mark(OSI_PROF_CONV_DGRAD, wt));
+        }
+        if (aside) {
+            if (hipEventRecord(n->ev_wt, n->side) != hipSuccess) return OSI_ERR_LAUNCH;
+            n->wt_pending = true;
+        }
+    }
     // stem
     if (image) OSI_TRY(osi_nchw3_to_nhwc4(image, ws + n->x4, n->B, n->H, n->W, st));
     Conv& c0 = n->convs[0];
@@ -718,9 +754,13 @@ static int dgrad_fused(osi_resnet50* n, int ci, const float* params, float* ws, 
     int P = 0;
     OSI_TRY(before_dgrad(n, st));
     // the in-block 3x3 / stride 1 input gradients (gate recomputed, one consumer, no addend) take the Winograd form
-    if (n->plan_knobs.dgrad_wino && f.scale0 && pd < 0 && addi < 0 && osi_conv_wino_eligible(&c.d, 1))
-        OSI_TRY(osi_conv_dgrad_fused_wino(&c.d, ws + n->scratch[dyi], params + c.w_off, ws + n->scratch[dxi], &f, ws + n->wino_ws,
-                                          n->wino_ws_bytes, &P, st));
+    if (n->wt_pending) {          // (forward Winograd off: nobody has waited for the side-stream weight transforms yet)
+        if (hipStreamWaitEvent(st, n->ev_wt, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+        n->wt_pending = false;
+    }
+    if (n->plan_knobs.dgrad_wino && f.scale0 && pd < 0 && addi < 0 && c.u_bw != (size_t)-1)
+        OSI_TRY(osi_conv_dgrad_fused_wino_pre(&c.d, ws + n->scratch[dyi], ws + c.u_bw, ws + n->scratch[dxi], &f, ws + n->wino_ws,
+                                              n->wino_ws_bytes, &P, st));
     else
     OSI_TRY(osi_conv_dgrad_fused(&c.d, ws + n->scratch[dyi], params + c.w_off, ws + n->scratch[dxi],
                                  addi >= 0 ? ws + n->scratch[addi] : nullptr, &f, OSI_TILE_AUTO, &P, st));
@@ -1062,6 +1102,7 @@ int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
     else if (!strcmp(name, "ds_sparse")) n->ds_sparse = value != 0;
     else if (!strcmp(name, "stem_wgrad_main")) n->stem_wgrad_main = value != 0;
     else if (!strcmp(name, "stage_join")) n->stage_join = value != 0;
+    else if (!strcmp(name, "wino_weights_aside")) n->wt_aside = value != 0;
 #ifdef OSI_DIAG
     else if (!strcmp(name, "dbg_skip")) n->dbg_skip = value;
 #endif

@@ -46,6 +46,11 @@ _SIGS = {
     "osi_conv_wino_workspace": (c_size_t, [_PD]),
     "osi_conv_fwd_wino": (c_int, [_PD, P, P, P, P, P, P, c_size_t, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
     "osi_conv_dgrad_fused_wino": (c_int, [_PD, P, P, P, P, P, c_size_t, POINTER(c_int), P]),
+    "osi_conv_wino_weights_bytes": (c_size_t, [_PD]),
+    "osi_conv_wino_slab_bytes": (c_size_t, []),
+    "osi_conv_wino_transform_weights": (c_int, [_PD, P, c_int, P, c_size_t, P]),
+    "osi_conv_fwd_wino_pre": (c_int, [_PD, P, P, P, P, P, P, c_size_t, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
+    "osi_conv_dgrad_fused_wino_pre": (c_int, [_PD, P, P, P, P, P, c_size_t, POINTER(c_int), P]),
     "osi_conv_wgrad_wino_workspace": (c_size_t, [_PD]),
     "osi_conv_wgrad_wino": (c_int, [_PD, P, P, P, P, P, P, c_size_t, P]),
     "osi_conv_fwd_bnstats_workspace": (c_size_t, [_PD]),

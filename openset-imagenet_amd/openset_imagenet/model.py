@@ -45,6 +45,7 @@ def debug_options_from_env():
         OSI_STEM_POOL_STATS=0 stem_pool_stats 0   bn1's backward reductions by their own pass instead of layer1.0.conv1's dgrad epilogue
         OSI_DS_SPARSE=0       ds_sparse 0         stride-2 shortcut gradients written / read as dense tensors (zero fill included)
         OSI_STEM_WGRAD_MAIN=0 stem_wgrad_main 0   the fused stem weight gradient queued on the side stream behind layer1's weight gradients
+        OSI_WINO_WEIGHTS_ASIDE=0 wino_weights_aside 0   the Winograd weight transforms of a training forward on the main stream (not beside the stem)
     (There is no switch for round 2's fused in-block activations: the unfused executor path no longer exists; its price on one box is the
     three-way A/B of the committed round-1 / round-2 / current trees, profiles/r03_ab_rounds.txt.)"""
     env = os.environ
@@ -68,6 +69,8 @@ def debug_options_from_env():
         out["stem_pool_stats"] = 0
     if env.get("OSI_DS_SPARSE") == "0":
         out["ds_sparse"] = 0
+    if env.get("OSI_WINO_WEIGHTS_ASIDE") == "0":
+        out["wino_weights_aside"] = 0
     if env.get("OSI_STEM_WGRAD_MAIN") == "0":
         out["stem_wgrad_main"] = 0
     return out

@@ -237,3 +237,32 @@ def test_weight_gradient_network_shapes_at_the_benchmarked_batch(cuda, C, H):
                                                 (5, 10, 6, 64, 64, True)])     # non-square
 def test_weight_gradient_ragged_and_odd_geometries(cuda, B, H, W, Cin, Cout, act):
     _wgrad(cuda, B, H, W, Cin, Cout, act, 1)
+
+
+def test_pretransformed_weights_give_the_same_bits(cuda):
+    """osi_conv_wino_transform_weights + the `_pre` calls (what the executor issues: every 3x3 layer's weights transformed on the side stream
+    at the start of a forward pass) = the self-contained calls, bit for bit."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    B, H, C = 16, 14, 128
+    g = _gen(cuda, "wino-pre")
+    d = N.ConvDesc.make(B, H, H, C, C, 3, 1, 1)
+    x = torch.randn(B, H, H, C, device=cuda, generator=g); w = torch.randn(C, 3, 3, C, device=cuda, generator=g) * 0.05
+    sc, sh = torch.rand(C, device=cuda, generator=g) + 0.5, torch.randn(C, device=cuda, generator=g) * 0.5
+    wb = L.osi_conv_wino_workspace(ctypes.byref(d)); ws = torch.empty(wb, dtype=torch.uint8, device=cuda)
+    ub, sb = L.osi_conv_wino_weights_bytes(ctypes.byref(d)), L.osi_conv_wino_slab_bytes()
+    assert ub == 16 * C * C * 4 and ub + sb == wb
+    u = torch.empty(ub, dtype=torch.uint8, device=cuda); slab = torch.empty(sb, dtype=torch.uint8, device=cuda)
+    ya, yb = torch.full((B, H, H, C), float("nan"), device=cuda), torch.full((B, H, H, C), float("nan"), device=cuda)
+    N.check(L.osi_conv_fwd_wino(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(w), N.ptr(ya), N.ptr(ws), wb, None, 0, None, None, T.S()))
+    N.check(L.osi_conv_wino_transform_weights(ctypes.byref(d), N.ptr(w), 0, N.ptr(u), ub, T.S()))
+    N.check(L.osi_conv_fwd_wino_pre(ctypes.byref(d), N.ptr(x), N.ptr(sc), N.ptr(sh), N.ptr(u), N.ptr(yb), N.ptr(slab), sb, None, 0, None, None, T.S()))
+    assert torch.equal(ya, yb)
+    y0 = torch.randn(B, H, H, C, device=cuda, generator=g)
+    f = T.Fusion(None, y0.data_ptr(), None, None, None, None, None, None, 0, sc.data_ptr(), sh.data_ptr())
+    P = ctypes.c_int()
+    N.check(L.osi_conv_dgrad_fused_wino(ctypes.byref(d), N.ptr(x), N.ptr(w), N.ptr(ya), ctypes.byref(f), N.ptr(ws), wb, ctypes.byref(P), T.S()))
+    N.check(L.osi_conv_wino_transform_weights(ctypes.byref(d), N.ptr(w), 1, N.ptr(u), ub, T.S()))
+    N.check(L.osi_conv_dgrad_fused_wino_pre(ctypes.byref(d), N.ptr(x), N.ptr(u), N.ptr(yb), ctypes.byref(f), N.ptr(slab), sb, ctypes.byref(P), T.S()))
+    assert torch.equal(ya, yb)
