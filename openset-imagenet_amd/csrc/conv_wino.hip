@@ -40,6 +40,20 @@ namespace {
 #ifndef OSI_WABL
 #define OSI_WABL 0
 #endif
+// the same for k_wino (forward / input gradient): 1 = U fragments from one cache-resident address, 2 = no patch loads inside the K loop,
+// 4 = no patch transform / LDS stores, 8 = no LDS operand reads, 16 = no epilogue arithmetic / stores
+#ifndef OSI_FABL
+#define OSI_FABL 0
+#endif
+// patch loads of the next slice: 0 = all sixteen at the top of a slice, n = spread over the first n positions (a burst blocks at the texture
+// addresser's queue: 8 is 5 - 8 % faster than 0 on the 28^2 / 14^2 / 7^2 layers, profiles/NOTES_r05.md)
+// output tile staged through LDS (1) or stored by its owner lanes (0)
+#ifndef OSI_STAGE_OUT
+#define OSI_STAGE_OUT 1
+#endif
+#ifndef OSI_XSPREAD
+#define OSI_XSPREAD 8
+#endif
 constexpr int KC = 16;      // channels per K slice
 constexpr int PF = 6;       // positions the U fragments are loaded ahead
 
@@ -181,12 +195,14 @@ __device__ __forceinline__ Seg seg_next(const Seg& c, int w, int nfull, int q, i
 
 // ---- epilogue of one channel quad (4 pixels x 4 consecutive channels of this lane's tile), shared by k_wino and k_wino_fixup -------------
 // Forward: y + optional (mean, M2) statistics per 16 tiles.
-template <bool ODD>
-__device__ __forceinline__ void epi0_quad(const WinoP& p, __amdgpu_buffer_rsrc_t ry, int g, f32x4 (&o)[4], const uint32_t (&po)[4], int ch0,
+// `put(k, g, v)` stores the 16 bytes of pixel k, channel quad g: straight to global memory (fix-up pass) or into the workgroup's LDS staging
+// tile, from where whole pixel rows leave in 16-byte lanes (k_wino: a lane's own stores go to 64 different 128-byte lines per instruction)
+template <bool ODD, class PUT>
+__device__ __forceinline__ void epi0_quad(const WinoP& p, PUT put, int g, f32x4 (&o)[4], const uint32_t (&po)[4], int ch0,
                                           int part, int lane) {
     {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bst4(ry, o[k], po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+        for (int k = 0; k < 4; ++k) put(k, g, o[k]);
         if (p.pmean) {
             // (mean, M2) of the group's valid pixels per channel: sum -> mean -> sum of squared deviations, every reduction a fixed-order
             // DPP row sum. Slots outside the image (ODD) are zeroed and their (0 - mean)^2 taken back out.
@@ -230,8 +246,8 @@ __device__ __forceinline__ Epi1Ops epi1_load(const WinoP& p, __amdgpu_buffer_rsr
     return L;
 }
 // g = gate . acc, gate = fma(y0, scale0, shift0) > 0 (the forward loader's own expression); sums of g and g * xhat0 per 64 pixels
-template <bool ODD>
-__device__ __forceinline__ void epi1_apply(const WinoP& p, __amdgpu_buffer_rsrc_t ry, int g, const f32x4 (&o)[4], const uint32_t (&po)[4],
+template <bool ODD, class PUT>
+__device__ __forceinline__ void epi1_apply(const WinoP& p, PUT put, int g, const f32x4 (&o)[4], const uint32_t (&po)[4],
                                            int ch0, int part, int lane, const Epi1Ops& L) {
     f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -245,7 +261,7 @@ __device__ __forceinline__ void epi1_apply(const WinoP& p, __amdgpu_buffer_rsrc_
             sg[e] += gv[e];
             sgx[e] += gv[e] * ((L.y0[k][e] - L.emu[e]) * L.einv[e]);
         }
-        bst4(ry, gv, po[k] == OOB ? OOB : po[k] + 32u * g, 0);
+        put(k, g, gv);
     }
     if (p.esum) {
 #pragma unroll
@@ -281,7 +297,9 @@ __device__ __forceinline__ void out_offsets(const WinoP& p, int mt, int nt, int 
 template <bool XF, int EPI, bool ODD, bool WIDE>
 __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
     constexpr int TB = WIDE ? 32 : 64, CW = WIDE ? 128 : 64, NV = WIDE ? 2 : 4;      // tiles / channels of a unit, channels per loader thread
-    __shared__ __attribute__((aligned(16))) float sV[2 * 16 * TB * KC];   // 128 KiB (64 KiB WIDE)
+    // V double buffer (2 x 64 KiB; 2 x 32 KiB WIDE) [+ WIDE: a 64 KiB output staging tile; the 64 x 64 form stages in the free V buffer]
+    __shared__ __attribute__((aligned(16))) float sV[2 * 16 * TB * KC + (WIDE ? 16384 : 0)];
+    __shared__ uint32_t sPo[256];        // byte offset of every pixel row of the unit's output tile (channel 0 of the unit), or OOB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = WIDE ? wave : wave >> 1, wn = WIDE ? 0 : wave & 1;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, p.y_bytes);
@@ -328,14 +346,15 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
 
     f32x16 acc[16];
     f32x4 xr[16];                    // WIDE: elements 0, 1 only
+    auto load_x1 = [&](int ks, int k) {
+        if constexpr (WIDE) {
+            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, off[k], (uint32_t)ks * (KC * 4), 0));
+            xr[k][0] = v[0]; xr[k][1] = v[1];
+        } else xr[k] = bld4(rx, off[k], (uint32_t)ks * (KC * 4));
+    };
     auto load_x = [&](int ks) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if constexpr (WIDE) {
-                const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, off[k], (uint32_t)ks * (KC * 4), 0));
-                xr[k][0] = v[0]; xr[k][1] = v[1];
-            } else xr[k] = bld4(rx, off[k], (uint32_t)ks * (KC * 4));
-        }
+        for (int k = 0; k < 16; ++k) load_x1(ks, k);
     };
     // activation (+ padding select) and column transform of patch column j. asm: IR passes otherwise regroup these scalar ops (SLP packs
     // them into v_pk_*, an anti-lever beside MFMAs, and sinks the selects to their users) whatever the machine scheduler is told.
@@ -393,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
     // U fragment ring: slot (pos % 16), loaded PF positions ahead across slice AND segment boundaries
     f32x4 a[16][2];
     auto load_u = [&](int pos, uint32_t base, int ks) {
-        const uint32_t soff = (uint32_t)(pos * p.KS + ks) * ustep;      // uniform: the scalar offset of the buffer load
+        const uint32_t soff = (OSI_FABL & 1) ? 0u : (uint32_t)(pos * p.KS + ks) * ustep;      // uniform: the scalar offset of the buffer load
         a[pos][0] = bld4(ru, base, soff);
         a[pos][1] = bld4(ru, base + 1024u, soff);
     };
@@ -420,7 +439,9 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                 ksn = nxt.valid ? nxt.ks0 : 0;
                 uan = nxt.valid ? ua_next : ua;
             }
+#if !(OSI_FABL & 2) && !OSI_XSPREAD
             load_x(ksn);
+#endif
             ld_scale(ksn, sc4, sh4);
             const float* r0 = rb0 + buf * (16 * TB * KC);
             const float* r1 = rb1 + buf * (16 * TB * KC);
@@ -430,8 +451,15 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                 constexpr int pos = decltype(POSC)::value;
                 if (pos + PF < 16) load_u(pos + PF, ua, ks);
                 else load_u(pos + PF - 16, uan, ksn);
+#if OSI_XSPREAD && !(OSI_FABL & 2)
+                if constexpr (pos < OSI_XSPREAD) {      // the next slice's 16 patch loads, a few behind each of the first positions
+                    constexpr int n0 = pos * 16 / OSI_XSPREAD, n1 = (pos + 1) * 16 / OSI_XSPREAD;
+#pragma unroll
+                    for (int k = n0; k < n1; ++k) load_x1(ksn, k);
+                }
+#endif
                 f32x4 nb0 = b0, nb1 = b1;
-                if (pos < 15) {
+                if (pos < 15 && !(OSI_FABL & 8)) {
                     nb0 = *reinterpret_cast<const f32x4*>(r0 + (pos + 1) * (TB * KC));
                     nb1 = *reinterpret_cast<const f32x4*>(r1 + (pos + 1) * (TB * KC));
                 }
@@ -440,8 +468,10 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                 for (int e = 0; e < 4; ++e) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[pos], 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[pos], 0, 0, 0);
+#if !(OSI_FABL & 4)
                 if constexpr (pos >= 8 && pos < 12) act_col(pos - 8, sc4, sh4);
                 if constexpr (pos >= 12) row_store(pos - 12, buf ^ 1);
+#endif
                 b0 = nb0; b1 = nb1;
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -457,8 +487,13 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
         const __amdgpu_buffer_rsrc_t r0y = make_rsrc(EPI == 1 ? p.ey0 : p.y, p.y_bytes);
         Epi1Ops L1{};
         if constexpr (EPI == 1) { if (seg.slot < 0) L1 = epi1_load(p, r0y, 0, po, ch0); }
+        float* const stage = WIDE ? sV + 2 * 16 * TB * KC : sV + (buf ^ 1) * (16 * TB * KC);      // free: the K loop's last barrier is behind us
+        if (seg.slot < 0 && wm == 0 && hh == 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+            for (int k = 0; k < 4; ++k) sPo[ntile * 4 + k] = po[k];       // (wm = 0, hh = 0: po is the offset of the unit's channel 0)
+        }
+#pragma unroll
+        for (int g = (OSI_FABL & 16) ? 3 : 0; g < 4; ++g) {
             f32x4 o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -466,7 +501,13 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                 float s[2][4];
 #pragma unroll
                 for (int nu = 0; nu < 4; ++nu) {
-                    const float m0 = acc[nu][r], m1 = acc[4 + nu][r], m2 = acc[8 + nu][r], m3 = acc[12 + nu][r];
+                    // the accumulators live in AGPRs; read HERE, one register at a time ("a" operand): left to itself the compiler copies all
+                    // sixteen tuples into VGPRs where the epilogue's control flow begins (256 moves + spills of the pipeline's live state)
+                    float m0, m1, m2, m3;
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m0) : "a"(acc[nu][r]));
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m1) : "a"(acc[4 + nu][r]));
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m2) : "a"(acc[8 + nu][r]));
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m3) : "a"(acc[12 + nu][r]));
                     s[0][nu] = m0 + m1 + m2;
                     s[1][nu] = m1 - m2 - m3;
                 }
@@ -477,10 +518,19 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                 }
             }
             if (seg.slot < 0) {
-                if constexpr (EPI == 0) epi0_quad<ODD>(p, ry, g, o, po, ch0, part, lane);
+                // into the staging tile [pixel row = 4 tile + k][CW channels], 16-byte chunks XOR-swizzled by the tile index
+                auto put = [&](int k, int gq, const f32x4& v) {
+#if OSI_STAGE_OUT
+                    const int chunk = (32 * wm + 8 * gq + 4 * hh) >> 2;
+                    *reinterpret_cast<f32x4*>(stage + (ntile * 4 + k) * CW + 4 * (chunk ^ (ntile & 15))) = v;
+#else
+                    bst4(ry, v, po[k] == OOB ? OOB : po[k] + 32u * gq, 0);
+#endif
+                };
+                if constexpr (EPI == 0) epi0_quad<ODD>(p, put, g, o, po, ch0, part, lane);
                 else {
                     const Epi1Ops Ln = epi1_load(p, r0y, g < 3 ? g + 1 : 3, po, ch0);      // the next quad's operands behind this quad's arithmetic
-                    epi1_apply<ODD>(p, ry, g, o, po, ch0, part, lane, L1);
+                    epi1_apply<ODD>(p, put, g, o, po, ch0, part, lane, L1);
                     L1 = Ln;
                 }
             } else {           // a piece of a remainder unit: the partial tile in register order (the output transform is linear)
@@ -488,6 +538,19 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) bst4(rs, o[k], so + (uint32_t)k * 1024u, 0);
             }
+        }
+        if (OSI_STAGE_OUT && seg.slot < 0) {
+            // whole pixel rows out of the staging tile: consecutive lanes = consecutive 16-byte chunks of a row (256 / 512 contiguous bytes)
+            __syncthreads();
+            constexpr int CPR = CW / 4, NCH = TB * 4 * CPR;      // chunks per row, chunks of the tile
+#pragma unroll 4
+            for (int it = 0; it < NCH / 256; ++it) {
+                const int idx = it * 256 + tid, row = idx / CPR, chunk = idx % CPR;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * CW + 4 * (chunk ^ ((row >> 2) & 15)));
+                const uint32_t base = sPo[row];
+                bst4(ry, v, base == OOB ? OOB : base + (uint32_t)chunk * 16u, 0);
+            }
+            __syncthreads();       // the next unit's K loop writes V into this region again
         }
         if (!nxt.valid) break;
         seg = nxt;
@@ -528,10 +591,11 @@ __global__ __launch_bounds__(64) void k_wino_fixup(WinoP p, int G) {
         b0 = b1;
     }
     const int ch0 = (WIDE ? 128 : 64) * nt + 32 * wm + 4 * hh, part = mt * (WIDE ? 2 : 4) + 2 * wn + ((lane >> 4) & 1);
-    if constexpr (EPI == 0) epi0_quad<ODD>(p, ry, g, o, po, ch0, part, lane);
+    auto put = [&](int k, int gq, const f32x4& v) { bst4(ry, v, po[k] == OOB ? OOB : po[k] + 32u * gq, 0); };
+    if constexpr (EPI == 0) epi0_quad<ODD>(p, put, g, o, po, ch0, part, lane);
     else {
         const Epi1Ops L = epi1_load(p, make_rsrc(p.ey0, p.y_bytes), g, po, ch0);
-        epi1_apply<ODD>(p, ry, g, o, po, ch0, part, lane, L);
+        epi1_apply<ODD>(p, put, g, o, po, ch0, part, lane, L);
     }
 }
 
