@@ -289,13 +289,20 @@ def _worker_body(cfg, log, out_dir, rank, world, distributed):
     # loaders (train.py:299-311). batch_size is per GPU; under data parallel every rank draws its own shard of each epoch
     sampler = torch.utils.data.distributed.DistributedSampler(train_ds, num_replicas=world, rank=rank, shuffle=True, seed=cfg.seed) \
         if distributed else None
-    lkw = dict(batch_size=cfg.batch_size, num_workers=cfg.workers, pin_memory=True)
+    prefetch = bool(getattr(cfg.data, "prefetch", True))   # new key: copy-stream prefetch + device-side crop / flip / ToTensor
+    # new key data.sub_batches: with the prefetcher and worker processes, the workers build batch_size / sub_batches samples at a time
+    # and the prefetcher stages sub_batches consecutive ones into one step's batch — the same batches (a sampler's index stream is only
+    # cut finer), a 1/sub_batches as long wait for the first batch of every epoch (profiles/r05_input_pipeline.json)
+    sub = int(getattr(cfg.data, "sub_batches", 4)) if (prefetch and cfg.workers > 0) else 1
+    if sub < 1 or cfg.batch_size % sub:
+        sub = 1
+    lkw = dict(batch_size=cfg.batch_size // sub, num_workers=cfg.workers, pin_memory=True)
     if cfg.workers > 0:
-        lkw.update(persistent_workers=True, prefetch_factor=4)
+        lkw.update(persistent_workers=True, prefetch_factor=4 * sub)   # the same number of samples ahead per worker
     train_loader = torch.utils.data.DataLoader(train_ds, shuffle=sampler is None, sampler=sampler, **lkw)
     val_loader = torch.utils.data.DataLoader(val_ds, **lkw)
-    if bool(getattr(cfg.data, "prefetch", True)):      # new key: copy-stream prefetch + device-side crop / flip / ToTensor
-        train_loader, val_loader = DevicePrefetcher(train_loader), DevicePrefetcher(val_loader)
+    if prefetch:
+        train_loader, val_loader = DevicePrefetcher(train_loader, group=sub), DevicePrefetcher(val_loader, group=sub)
 
     # number of classes / loss (train.py:329-347): entropic has no output for the unknown label
     n_classes = train_table.label_count - 1 if cfg.loss.type == "entropic" else train_table.label_count

@@ -177,6 +177,24 @@ def test_prefetcher_equals_synchronous_loop(cuda):
     b = epoch([(x, y) for x, y in sync])
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and np.isfinite(a[2])
 
+    # sub-batches (worker()'s data.sub_batches): loaders of batch 2 (shuffled by the same generator seed; one with worker processes)
+    # grouped in pairs yield the batches of the batch-4 loader, ragged tail (22 = 5 * 4 + 2) included; so do plain (images, labels) pairs
+    for nw in (0, 2):
+        shuf = lambda bs, nw=nw: torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=True, num_workers=nw if bs == 2 else 0, pin_memory=True,
+                                                             generator=torch.Generator().manual_seed(5))
+        whole = [(x.clone(), y.clone()) for x, y in P.DevicePrefetcher(shuf(4))]
+        fine = P.DevicePrefetcher(shuf(2), group=2)
+        parts = [(x.clone(), y.clone()) for x, y in fine]
+        assert len(fine) == len(parts) == len(whole) == 6 and parts[-1][0].shape[0] == 2
+        for (a, ya), (b, yb) in zip(parts, whole):
+            assert a.shape == b.shape and torch.equal(a, b) and torch.equal(ya, yb)
+    pairs = torch.utils.data.TensorDataset(torch.randn(n, 3, 8, 8, generator=g), lab)
+    whole = [(x.clone(), y.clone()) for x, y in P.DevicePrefetcher(torch.utils.data.DataLoader(pairs, batch_size=6))]
+    parts = [(x.clone(), y.clone()) for x, y in P.DevicePrefetcher(torch.utils.data.DataLoader(pairs, batch_size=2), group=3)]
+    assert len(parts) == len(whole) == 4 and all(torch.equal(a, b) and torch.equal(ya, yb) for (a, ya), (b, yb) in zip(parts, whole))
+    with pytest.raises(ValueError):
+        P.DevicePrefetcher(mk(), group=0)
+
 
 def test_metrics_module_matches_reference_vectors(cuda, golden_dir):
     """metrics.confidence(scores, target, offset, unknown_class, last_valid_class) — the reference's own signature

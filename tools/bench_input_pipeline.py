@@ -81,6 +81,7 @@ def main():
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else min(16, os.cpu_count() or 4)
     nice = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] != "-" else None          # niceness of the decode workers (pipeline.worker_init); default: none
     quick = len(sys.argv) > 5 and sys.argv[5] == "quick"            # only synthetic / loader-only / canvas + prefetch
+    sub = int(sys.argv[6]) if len(sys.argv) > 6 else 4              # sub-batches per step (train.py's data.sub_batches)
     from PIL import Image
     from openset_imagenet import ResNet50, EntropicOpensetLoss, AverageMeter, optim, tools, pipeline as P
     from openset_imagenet.train import train
@@ -99,12 +100,12 @@ def main():
         csv = os.path.join(d, "p2_train.csv")
         open(csv, "w").write("\n".join(rows) + "\n")
 
-        def loader(uint8, nw=None, nice=nice):
+        def loader(uint8, nw=None, nice=nice, sub=1):
             nw = workers if nw is None else nw
             ds = P.CanvasDataset(csv, d, True, "entropic", uint8)
             import functools
-            return torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True, num_workers=nw, pin_memory=True, drop_last=True,
-                                               persistent_workers=nw > 0, prefetch_factor=4 if nw > 0 else None,
+            return torch.utils.data.DataLoader(ds, batch_size=B // sub, shuffle=True, num_workers=nw, pin_memory=True, drop_last=True,
+                                               persistent_workers=nw > 0, prefetch_factor=4 * sub if nw > 0 else None,
                                                worker_init_fn=None if nice is None else functools.partial(P.worker_init, niceness=nice))
 
         class Staged:      # canvas batches staged inside the step (no copy stream): isolates what the prefetch adds
@@ -174,8 +175,18 @@ def main():
             out["train_canvas_img_s"] = round(epoch(Staged(canv)), 1)
             note("reference-style / staged done")
         out["train_canvas_prefetch_img_s"] = round(epoch(P.DevicePrefetcher(canv)), 1)
+        note("prefetch done")
+        if sub > 1 and B % sub == 0:                 # what worker() builds by default: sub-batches grouped by the prefetcher
+            fine = P.DevicePrefetcher(loader(True, sub=sub), group=sub)
+            epoch(fine)                              # worker start-up
+            out["sub_batches"] = sub
+            out["train_canvas_prefetch_sub_img_s"] = round(epoch(fine), 1)
+            out["train_canvas_prefetch_sub_img_s_2nd"] = round(epoch(fine), 1)
         out["train_synthetic_resident_img_s_after"] = round(epoch(Resident(len(canv))), 1)
         out["end_to_end_vs_synthetic"] = round(out["train_canvas_prefetch_img_s"] / out["train_synthetic_resident_img_s"], 4)
+        if "train_canvas_prefetch_sub_img_s" in out:
+            out["end_to_end_vs_synthetic_sub"] = round(max(out["train_canvas_prefetch_sub_img_s"], out["train_canvas_prefetch_sub_img_s_2nd"])
+                                                       / out["train_synthetic_resident_img_s"], 4)
         print(json.dumps(out))
 
 
