@@ -57,11 +57,13 @@ def test_model_accepts_uint8_batches(cuda):
         model(outs[0][0].new_zeros(2, 3, 64, 64), flip=[0, 1])        # flip flags need the uint8 route
 
 
-@pytest.mark.parametrize("u8", [True, False])
-def test_worker_on_jpeg_files(cuda, tmp_path, u8):
+@pytest.mark.parametrize("u8,workers", [(True, 0), (False, 0), (True, 2)])
+def test_worker_on_jpeg_files(cuda, tmp_path, u8, workers):
     """The reference's data contract end to end (CSV of relative JPEG paths + labels, Resize(256) / crop / flip on the host
     workers, train.py:259-311) through worker(): with the default uint8 hand-over ToTensor runs on the GPU, with data.uint8 off
-    the samples are fp32 CHW like the reference's; both train one epoch, validate, and write the checkpoints."""
+    the samples are fp32 CHW like the reference's; both train one epoch, validate, and write the checkpoints. With worker processes
+    the loader builds sub-batches (data.sub_batches, default 4: here single samples) that the prefetcher groups back into batches
+    of 4 — the ragged tails (10 = 2 * 4 + 2 training, 6 = 4 + 2 validation samples) included."""
     import os
     from PIL import Image
     from openset_imagenet import util
@@ -81,7 +83,7 @@ def test_worker_on_jpeg_files(cuda, tmp_path, u8):
     (proto / "p2_val.csv").write_text("\n".join(rows["val"]) + "\n")
     (proto / "p2_test.csv").write_text("\n".join(rows["test"]) + "\n")
     cfg = util.load_yaml(os.path.join(os.path.dirname(__file__), "..", "config", "train.yaml"))
-    cfg.epochs, cfg.batch_size, cfg.workers, cfg.parallel, cfg.gpu, cfg.protocol = 1, 4, 0, True, 0, 2
+    cfg.epochs, cfg.batch_size, cfg.workers, cfg.parallel, cfg.gpu, cfg.protocol = 1, 4, workers, True, 0, 2
     cfg.loss.type = cfg.name = "entropic"
     cfg.data.imagenet_path = str(img_dir)
     cfg.data.train_file, cfg.data.val_file = str(proto / "p{}_train.csv"), str(proto / "p{}_val.csv")
@@ -91,7 +93,7 @@ def test_worker_on_jpeg_files(cuda, tmp_path, u8):
     assert np.isfinite(best)
     ck = torch.load(tmp_path / "out" / "entropic_curr.pth", weights_only=False)
     assert ck["epoch"] == 1 and ck["model_state_dict"]["logits.weight"].shape[0] == 3      # 3 known classes, -1 = negatives
-    if u8:   # the reference's evaluate.py surface on the checkpoint just written: arrays of both splits + the OSCR curve
+    if u8 and not workers:   # the reference's evaluate.py surface on the checkpoint just written: arrays of both splits + the OSCR curve
         from openset_imagenet.script import evaluate
         from openset_imagenet.util import calculate_oscr
         from oracle.oscr_oracle import calculate_oscr as oracle_oscr
