@@ -190,6 +190,20 @@ if os.environ.get("OSI_BENCH_CPUS") and hasattr(os, "sched_setaffinity"):
     except OSError:
         pass
 
+# a rank started by somebody else's launcher (`python -m torch.distributed.run ... bench.py --gpus N`, the driver's form) takes the share
+# the self-launcher would have given it: same plan, computed by every rank from the mask they all inherited (OSI_BENCH_BIND=none: off)
+elif int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("LOCAL_RANK") is not None and hasattr(os, "sched_setaffinity") \
+        and os.environ.get("OSI_BENCH_BIND", "auto") != "none":
+    try:
+        _lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
+        _plan, _policy = plan_rank_cpus(_lw, os.environ.get("OSI_BENCH_BIND", "auto"))
+        if _plan is not None and _plan[int(os.environ["LOCAL_RANK"])]:
+            os.sched_setaffinity(0, _plan[int(os.environ["LOCAL_RANK"])])
+            BOUND_CPUS = sorted(os.sched_getaffinity(0))
+            os.environ.setdefault("OSI_BENCH_BIND_POLICY", "rank-side:" + _policy)
+    except (OSError, ValueError, IndexError):
+        pass
+
 # RCCL has no API for its channel count (= the workgroups a collective keeps resident on this GPU): every rank reads it from the
 # communicator's own INIT log, written to a private file (stdout stays one JSON line). Set before torch loads RCCL.
 RCCL_LOG = None

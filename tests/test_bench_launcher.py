@@ -87,3 +87,25 @@ def test_reserved_cus_follow_the_channel_count():
     sys.path.insert(0, os.path.join(ROOT, "openset-imagenet_amd"))
     from openset_imagenet.dp import reserved_cus_for_channels
     assert [reserved_cus_for_channels(c) for c in (None, 0, 1, 8, 9, 32, 128, 1000)] == [0, 0, 1, 1, 2, 4, 16, 32]
+
+
+def test_rank_under_an_external_launcher_takes_its_own_cpu_share():
+    """`python -m torch.distributed.run ... bench.py --gpus N` (the driver's form for N > 1) does not pass through launch_ranks: every
+    rank then binds itself to the share the self-launcher would have dealt it, before torch loads; OSI_BENCH_BIND=none turns it off."""
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) < 2:
+        return
+    code = f"import importlib.util as u, os; s = u.spec_from_file_location('b', {BENCH!r}); m = u.module_from_spec(s); s.loader.exec_module(m); " \
+           "print('CPUS', m.BOUND_CPUS, os.environ.get('OSI_BENCH_BIND_POLICY'))"
+    shares = []
+    for rank in (0, 1):
+        r = subprocess.run([sys.executable, "-c", code], env=_clean_env(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2",
+                                                                         OSI_BENCH_BIND="even"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        line = [l for l in r.stdout.splitlines() if l.startswith("CPUS")][-1]
+        shares.append(eval(line[5:line.rindex("]") + 1]))
+        assert line.endswith("rank-side:even")
+    assert shares[0] == mine[:len(mine) // 2] and shares[1] == mine[len(mine) // 2:2 * (len(mine) // 2)]
+    r = subprocess.run([sys.executable, "-c", code], env=_clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", OSI_BENCH_BIND="none"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CPUS None None" in r.stdout
