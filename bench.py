@@ -83,6 +83,9 @@ def plan_rank_cpus(n_ranks, policy="auto"):
     return [mine[r * per:(r + 1) * per] for r in range(n_ranks)], "even"
 
 
+MIN_CPU_SHARE = 4     # a rank is only bound when its share holds its launch thread, RCCL's proxy thread and the copy / logging helpers
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no rank variables in the environment: start the N ranks as CHILD processes of this
     one (one process per GPU, the reference's intent: config/train.yaml:18,35-39, script/train_all.py:96-99), relay rank 0's single
@@ -102,6 +105,8 @@ def launch_ranks(n, argv):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cpus, policy = plan_rank_cpus(n, la.bind)
+    if cpus and min(len(c) for c in cpus) < MIN_CPU_SHARE:
+        cpus, policy = None, f"none (a share would be < {MIN_CPU_SHARE} CPUs)"
     procs = []
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -191,13 +196,14 @@ if os.environ.get("OSI_BENCH_CPUS") and hasattr(os, "sched_setaffinity"):
         pass
 
 # a rank started by somebody else's launcher (`python -m torch.distributed.run ... bench.py --gpus N`, the driver's form) takes the share
-# the self-launcher would have given it: same plan, computed by every rank from the mask they all inherited (OSI_BENCH_BIND=none: off)
+# the self-launcher would have given it: same plan, computed by every rank from the mask they all inherited (--bind none / OSI_BENCH_BIND=none: off)
 elif int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("LOCAL_RANK") is not None and hasattr(os, "sched_setaffinity") \
-        and os.environ.get("OSI_BENCH_BIND", "auto") != "none":
+        and os.environ.get("OSI_BENCH_LAUNCHED") != "1":         # (the self-launcher has decided for its own children)
     try:
+        _bind = sys.argv[sys.argv.index("--bind") + 1] if "--bind" in sys.argv[:-1] else os.environ.get("OSI_BENCH_BIND", "auto")
         _lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
-        _plan, _policy = plan_rank_cpus(_lw, os.environ.get("OSI_BENCH_BIND", "auto"))
-        if _plan is not None and _plan[int(os.environ["LOCAL_RANK"])]:
+        _plan, _policy = plan_rank_cpus(_lw, _bind if _bind in ("auto", "near", "even", "none") else "auto")
+        if _plan is not None and min(len(c) for c in _plan) >= MIN_CPU_SHARE:
             os.sched_setaffinity(0, _plan[int(os.environ["LOCAL_RANK"])])
             BOUND_CPUS = sorted(os.sched_getaffinity(0))
             os.environ.setdefault("OSI_BENCH_BIND_POLICY", "rank-side:" + _policy)
