@@ -56,7 +56,8 @@ const char* osi_strerror(int code);
  *   dgrad_wino *     0 | 1         1        the same for the in-block fused 3x3 stride-1 input gradients (osi_conv_dgrad_fused_wino)
  *   wgrad_wino *     0 | 1         1        the executor's 3x3 stride-1 weight gradients in the Winograd F(3x3,2x2) form (osi_conv_wgrad_wino)
  *   wino_wide        0 | 1         1        Winograd forward / input gradient: units of 32 tiles x 128 channels (instead of 64 x 64) where the channel count allows
- *   wino_streamk     0 | 1         1        Winograd forms: the units of the ragged last round are cut along K over all workgroups (fix-up pass); 0 = whole units
+ *   wino_streamk     0 .. 3        2        Winograd forms: the units of the ragged last round are cut along K over all workgroups (fix-up pass): 0 = whole
+ *                                           units only, 1 = forward and input gradient, 2 = forward only, 3 = input gradient only
  *   bn_grid          1 .. 2^20     1024     grid cap of the BatchNorm stream kernels
  *   bn_grid_bwd      1 .. 2^20     1024     the same for the backward apply kernels
  *   bn_single_p      1 .. 2^20     128      BatchNorm partials merged by ONE 256-thread launch up to this many row tiles

@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1, /*tail_gain*/ 8, /*tail_qmax*/ 8, /*bn_grid_bwd*/ 1024, /*bn_wide_p*/ 2048, /*fwd_rows*/ 1, /*fwd_w3*/ 1, /*dgrad_w3*/ 1, /*fwd_wino*/ 1, /*dgrad_wino*/ 1, /*wgrad_wino*/ 1, /*wino_wide*/ 1, /*wino_streamk*/ 1, /*dp_reserved_cus*/ 0};
+OsiTuning g_osi_tuning = {/*wgrad_tile*/ 0, /*wgrad_blocks*/ 2048, /*wgrad_nst*/ 1, /*bn_grid*/ 1024, /*bn_single_p*/ 128, /*wgrad3*/ 2, /*wgrad3_blocks*/ 768, /*fwd_wide*/ 0, /*dgrad_wide*/ 0, /*wgrad_group*/ 2, /*tail_split*/ 1, /*tail_cus*/ 0, /*tail_smax*/ 8, /*tail_mint*/ 16, /*stem_direct*/ 1, /*tail_gain*/ 8, /*tail_qmax*/ 8, /*bn_grid_bwd*/ 1024, /*bn_wide_p*/ 2048, /*fwd_rows*/ 1, /*fwd_w3*/ 1, /*dgrad_w3*/ 1, /*fwd_wino*/ 1, /*dgrad_wino*/ 1, /*wgrad_wino*/ 1, /*wino_wide*/ 1, /*wino_streamk*/ 2, /*dp_reserved_cus*/ 0};
 
 namespace {
 int* tuning_slot(const char* name) {
@@ -56,7 +56,8 @@ int osi_set_tuning(const char* name, int value) {
     else if (s == &t.bn_single_p) good = in(1, 1 << 20);
     else if (s == &t.bn_wide_p) good = in(0, 2048);
     else if (s == &t.wgrad3 || s == &t.wgrad_group) good = in(0, 2);
-    else if (s == &t.fwd_wide || s == &t.dgrad_wide || s == &t.tail_split || s == &t.stem_direct || s == &t.fwd_w3 || s == &t.dgrad_w3 || s == &t.fwd_wino || s == &t.dgrad_wino || s == &t.wino_streamk || s == &t.wgrad_wino || s == &t.wino_wide) good = in(0, 1);
+    else if (s == &t.fwd_wide || s == &t.dgrad_wide || s == &t.tail_split || s == &t.stem_direct || s == &t.fwd_w3 || s == &t.dgrad_w3 || s == &t.fwd_wino || s == &t.dgrad_wino || s == &t.wgrad_wino || s == &t.wino_wide) good = in(0, 1);
+    else if (s == &t.wino_streamk) good = in(0, 3);
     else if (s == &t.tail_cus) good = in(0, 4096);            // 0 = ask the device
     else if (s == &t.tail_smax) good = in(1, 64);
     else if (s == &t.tail_mint) good = in(1, 4096);

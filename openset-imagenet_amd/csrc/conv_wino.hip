@@ -925,14 +925,18 @@ size_t u_bytes_of(const osi_conv_desc* d) { return ((size_t)16 * d->Cin * d->Cou
 size_t slab_bytes_of() { return (size_t)(hw_cus() / 8 * 8 < 8 ? 8 : hw_cus() / 8 * 8) * 2 * SLOT_BYTES; }
 
 // q full rounds + r remainder units over G workgroups; slab behind the transformed weights
-void plan_units(WinoP& p, void* slab, const osi_conv_desc* d, int G) {
+void plan_units(WinoP& p, void* slab, const osi_conv_desc* d, int G, bool input_gradient) {
     const int V = p.MT * p.NT;
     p.q = V / G; p.r = V - p.q * G; p.nfull = p.q * G;
     // short units (KS <= 4: the 64-channel layers) keep their ragged last round: a piece of one or two slices plus the fix-up pass costs
     // what the balance returns (measured: 205 vs 205 us forward, 232 vs 228 us input gradient at 56 x 56)
     // — unless the ragged round is a large part of a short launch (small batches: B = 64 leaves 16 units for a 4th round of 3.06)
     const bool heavy_tail = p.r > 0 && (double)(G - p.r) / (double)G / (double)(p.q + 1) >= 0.15;
-    if (!g_osi_tuning.wino_streamk || (p.KS <= 4 && !heavy_tail)) { p.nfull = V; p.r = 0; }
+    // knob wino_streamk: 0 = never, 1 = both directions, 2 = forward only, 3 = input gradient only (in the backward pass the weight
+    // gradients of the side stream fill the CUs a ragged round leaves idle; the forward has nothing beside it)
+    const int sk = g_osi_tuning.wino_streamk;
+    const bool cut = sk == 1 || (sk == 2 && !input_gradient) || (sk == 3 && input_gradient);
+    if (!cut || (p.KS <= 4 && !heavy_tail)) { p.nfull = V; p.r = 0; }
     p.slab = (float*)slab;
     p.slab_bytes = (int)((size_t)G * 2 * SLOT_BYTES);
 }
@@ -979,7 +983,7 @@ static int fwd_wino_impl(const osi_conv_desc* d, const float* x, const float* in
     }
     if (w) { if (int e = launch_weights<0>(w, u, d->Cin, d->Cout, st)) return e; }
     const int G = wino_grid();
-    plan_units(p, slab, d, G);
+    plan_units(p, slab, d, G, false);
     const dim3 grid((unsigned)G), blk(256);
     const bool wide = wide_units(d->Cout), odd = g.odd || (wide && g.T % 32 != 0);
     auto launch = [&](auto XFC, auto ODDC, auto WIDEC) {
@@ -1052,7 +1056,7 @@ static int dgrad_wino_impl(const osi_conv_desc* d, const float* dy, const float*
     *P = g.P;
     if (w) { if (int e = launch_weights<1>(w, u, d->Cout, d->Cin, st)) return e; }
     const int G = wino_grid();
-    plan_units(p, slab, d, G);
+    plan_units(p, slab, d, G, true);
     const dim3 grid((unsigned)G), blk(256);
     const bool wide = wide_units(d->Cin), odd = g.odd || (wide && g.T % 32 != 0);
     auto launch = [&](auto ODDC, auto WIDEC) {

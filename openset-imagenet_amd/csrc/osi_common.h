@@ -48,7 +48,7 @@ struct OsiTuning {
     int dgrad_wino;       // dgrad: the same for the in-block fused 3x3 stride-1 input gradients
     int wgrad_wino;       // wgrad: the executor's 3x3 stride-1 weight gradients (conv2, fused input activation) in the Winograd F(3x3,2x2) form
     int wino_wide;        // Winograd fwd / dgrad: units of 32 tiles x 128 channels where the channel count allows (the patch transform serves 2x the channels)
-    int wino_streamk;     // Winograd forms: 1 = the units of the ragged last round are cut along K over all workgroups (stream-K), 0 = whole units only
+    int wino_streamk;     // Winograd forms: the units of the ragged last round are cut along K over all workgroups (stream-K): 0 = never, 1 = forward and input gradient, 2 = forward only (default), 3 = input gradient only
     int dp_reserved_cus;  // CUs' worth of wave slots the launch plans leave to co-resident communication kernels (data parallel); 0 = none
 };
 extern OsiTuning g_osi_tuning;

@@ -20,6 +20,20 @@ from test_production_shapes_gpu import _bound, _check_partials_and_finalize, _co
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(autouse=True)
+def _both_directions_cut():
+    """The product default cuts the ragged round stream-K style in the FORWARD only (wino_streamk = 2: in the backward pass the side
+    stream's weight gradients fill the idle CUs and the cut costs more than it returns); these tests run with 1 = both directions, so
+    that the input gradient's pieces + fix-up stay covered. The whole-network tests run at the default, the knob matrix at 0, 1 and 3."""
+    from openset_imagenet import _native as N
+    L = N.lib()
+    prev = ctypes.c_int()
+    N.check(L.osi_get_tuning(b"wino_streamk", ctypes.byref(prev)))
+    N.check(L.osi_set_tuning(b"wino_streamk", 1))
+    yield
+    N.check(L.osi_set_tuning(b"wino_streamk", prev.value))
+
+
 # (C, H): the four 3x3 stride-1 layer shapes of the network (SURVEY.md Appendix A)
 NETWORK = [(64, 56), (128, 28), (256, 14), (512, 7)]
 
