@@ -857,11 +857,12 @@ __global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restri
     }
 }
 
+int backward_exclusive_cus();
 struct WgradPlan { int S, steps; size_t slab_floats; };
 WgradPlan plan_wgrad_wino(const osi_conv_desc* d) {
     const int T = d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
     const int blocks = (d->Cout / 64) * (d->Cin / 64);
-    int G = hw_cus();
+    int G = backward_exclusive_cus();      // blocks x splits = the CUs this backward-pass kernel may count on (see there)
     int S = G / blocks;
     if (S < 1) S = 1;
     const int max_s = (T + 63) / 64;                 // at least 8 K steps per split
@@ -915,9 +916,22 @@ WinoP make_wp(const osi_conv_desc* d, const Geo& g, int Kc, int Nc) {
     return p;
 }
 
-// persistent grid: one workgroup per CU the launch plans may use, a multiple of 8 (a workgroup's units keep its blockIdx % 8 = its XCD)
-int wino_grid() {
-    int cus = chip_cus() / 8 * 8;
+// CUs the Winograd kernels of the BACKWARD pass may count on while data-parallel collectives are in flight. These kernels are one
+// 512-register workgroup per CU: a CU that holds ONE resident RCCL channel workgroup is lost to them entirely (the direct kernels, 8
+// waves per SIMD, lose an eighth of it — what dp_reserved_cus = ceil(channels / 8) was sized for), and a workgroup that finds no CU runs in
+// a second round. So they leave the CHANNEL count free (8 x dp_reserved_cus, at most a quarter of the chip). The forward pass has no
+// collective beside it and keeps the fwd / dgrad plans' figure. Measured at world size 1 (profiles/r05_ab_dp_reserved.txt): 32 CUs less
+// cost the overlapped step 0.0 - 0.25 ms.
+int backward_exclusive_cus() {
+    if (g_osi_tuning.tail_cus > 0) return chip_cus();
+    int res = 8 * g_osi_tuning.dp_reserved_cus;
+    if (res > hw_cus() / 4) res = hw_cus() / 4;
+    const int n = hw_cus() - res;
+    return n < 8 ? 8 : n;
+}
+// persistent grid: one workgroup per CU the launch may use, a multiple of 8 (a workgroup's units keep its blockIdx % 8 = its XCD)
+int wino_grid(bool backward) {
+    int cus = (backward ? backward_exclusive_cus() : chip_cus()) / 8 * 8;
     return cus < 8 ? 8 : cus;
 }
 constexpr size_t SLOT_BYTES = 65536;      // one partial tile: 256 pixels x 64 channels, fp32
@@ -982,7 +996,7 @@ static int fwd_wino_impl(const osi_conv_desc* d, const float* x, const float* in
         *P = g.P; *rows_per_block = (int)g.cnt;
     }
     if (w) { if (int e = launch_weights<0>(w, u, d->Cin, d->Cout, st)) return e; }
-    const int G = wino_grid();
+    const int G = wino_grid(false);
     plan_units(p, slab, d, G, false);
     const dim3 grid((unsigned)G), blk(256);
     const bool wide = wide_units(d->Cout), odd = g.odd || (wide && g.T % 32 != 0);
@@ -1055,7 +1069,7 @@ static int dgrad_wino_impl(const osi_conv_desc* d, const float* dy, const float*
     }
     *P = g.P;
     if (w) { if (int e = launch_weights<1>(w, u, d->Cout, d->Cin, st)) return e; }
-    const int G = wino_grid();
+    const int G = wino_grid(true);
     plan_units(p, slab, d, G, true);
     const dim3 grid((unsigned)G), blk(256);
     const bool wide = wide_units(d->Cin), odd = g.odd || (wide && g.T % 32 != 0);
