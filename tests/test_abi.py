@@ -83,3 +83,29 @@ def test_executor_layout_matches_reference_state_dict():
         assert lib.osi_resnet50_backward(h, 16, 16, 16, 16, None, 0, 1, None) == -3
     finally:
         lib.osi_resnet50_destroy(h)
+
+
+def test_backward_winograd_plans_leave_the_channel_count_of_cus_free():
+    """Host logic only (no launch): under data parallelism the backward-pass Winograd kernels — one 512-register workgroup per CU —
+    plan for hw_cus - 8 * dp_reserved_cus CUs (a CU holding one resident RCCL channel workgroup cannot host them at all), capped at a
+    quarter of the chip; the weight gradient's split count, hence its workspace, shows the plan. Without a device the library assumes
+    the MI355X's 256 CUs."""
+    from openset_imagenet import _native as N
+    L = N.lib()
+    per_split = 9 * 4096 * 4                                   # one [9][64][64] fp32 partial
+    d1 = N.ConvDesc.make(128, 56, 56, 64, 64, 3, 1, 1)         # 1 block  -> splits = CUs
+    d16 = N.ConvDesc.make(128, 14, 14, 256, 256, 3, 1, 1)      # 16 blocks -> splits = CUs / 16
+    prev = ctypes.c_int()
+    N.check(L.osi_get_tuning(b"dp_reserved_cus", ctypes.byref(prev)))
+    try:
+        seen = {}
+        for reserved in (0, 4, 8, 32):
+            N.check(L.osi_set_tuning(b"dp_reserved_cus", reserved))
+            seen[reserved] = (L.osi_conv_wgrad_wino_workspace(ctypes.byref(d1)) // per_split,
+                              L.osi_conv_wgrad_wino_workspace(ctypes.byref(d16)) // per_split)
+    finally:
+        N.check(L.osi_set_tuning(b"dp_reserved_cus", prev.value))
+    import torch
+    if not torch.cuda.is_available():                          # 256 CUs assumed
+        assert seen == {0: (256, 256), 4: (224, 224), 8: (192, 192), 32: (192, 192)}, seen
+    assert seen[0][0] > seen[4][0] > seen[8][0] == seen[32][0] and seen[0][0] - seen[4][0] == 32
