@@ -109,3 +109,29 @@ def test_rank_under_an_external_launcher_takes_its_own_cpu_share():
     r = subprocess.run([sys.executable, "-c", code], env=_clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", OSI_BENCH_BIND="none"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "CPUS None None" in r.stdout
+
+
+def test_near_binding_deals_a_locality_domain_out_among_its_ranks(monkeypatch):
+    """The "near" plan on a made-up topology (sysfs is not consulted): ranks whose GPUs share a locality domain split that domain's
+    CPUs evenly; a domain with fewer CPUs than ranks, an unresolved GPU, or a visibility mask fall back to the even split."""
+    b = _bench_module()
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) < 4:
+        return
+    half = len(mine) // 2
+    dom = [mine[:half], mine[half:2 * half]]
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(b, "_cpus_near_gpu", lambda r: dom[r // 2] if r < 4 else None)
+    cpus, policy = b.plan_rank_cpus(4, "near")               # GPUs 0, 1 near domain 0; GPUs 2, 3 near domain 1
+    if half >= 2:
+        assert policy == "near"
+        per = half // 2
+        assert cpus == [dom[0][:per], dom[0][per:2 * per], dom[1][:per], dom[1][per:2 * per]]
+    cpus, policy = b.plan_rank_cpus(8, "auto")               # GPUs 4..7 do not resolve
+    assert policy in ("even", "none")
+    monkeypatch.setattr(b, "_cpus_near_gpu", lambda r: mine[:1])     # eight ranks on a one-CPU domain
+    assert b.plan_rank_cpus(2, "near")[1] == "even"
+    monkeypatch.setattr(b, "_cpus_near_gpu", lambda r: dom[r % 2])
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")          # a mask may have reordered the devices: sysfs order is not HIP's
+    assert b.plan_rank_cpus(2, "auto")[1] == "even"
