@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the bucketed gradient averaging of dp.py equals the single-process mean, bucket by bucket, on
+"""CPU, world_size 2 and 4 over gloo: the bucketed gradient averaging of dp.py equals the single-process mean, bucket by bucket, on
 gradients computed by the oracle from different per-rank batches; parameters and BN buffers are broadcast from rank 0."""
 import os
 import socket
@@ -45,12 +45,16 @@ def _worker(rank, world, port, out):
         allg = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allg, mine)
         expect = sum(allg) / world
+        # world 2: a + b has one rounding whatever the order — the average matches to the last bit; more ranks: the collective's
+        # summation order differs from Python's, each side makes (world - 1) roundings of at most 2^-24 of the sum of magnitudes
+        bound = (world - 2) * 2.0 ** -22 * sum(a.abs() for a in allg) / world + 1e-7
+        close = lambda got: bool(((got - expect).abs() <= bound).all())
         # the schedule the executor drives: one bucket per backward stage, head first
         buckets = model.gradient_buckets()
         for lo, hi in buckets:
             ddp.sync.bucket_ready(model.flat_gradients(), lo, hi)
         ddp.sync.finish()
-        assert torch.allclose(model.flat_gradients(), expect, rtol=0, atol=1e-7)
+        assert close(model.flat_gradients())
         assert sorted(buckets)[0][0] == 0 and max(h for _, h in buckets) == mine.numel()
         # instrumented form of the same schedule (bench.py's comm leg): same averages, and the timing record has its fields
         with torch.no_grad():
@@ -61,16 +65,17 @@ def _worker(rank, world, port, out):
         ddp.sync.finish()
         t = ddp.sync.read_timing()
         ddp.sync.timing(False)
-        assert torch.allclose(model.flat_gradients(), expect, rtol=0, atol=1e-7)
+        assert close(model.flat_gradients())
         assert t["steps"] == 1 and t["exposed_comm_ms"] is not None and t["exposed_comm_ms"] >= 0 and t["comm_ms_per_step"] is None
-        out.put((rank, float((model.flat_gradients() - expect).abs().max())))
+        out.put((rank, float(((model.flat_gradients() - expect).abs() - bound).max())))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_bucketed_gradient_average_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_gradient_average(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
@@ -80,4 +85,4 @@ def test_bucketed_gradient_average_world2():
         p.join(540)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     res = sorted(out.get(timeout=5) for _ in range(world))
-    assert [r for r, _ in res] == [0, 1] and all(e <= 1e-7 for _, e in res)
+    assert [r for r, _ in res] == list(range(world)) and all(e <= 0 for _, e in res)
