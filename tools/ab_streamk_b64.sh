@@ -1,3 +1,5 @@
+#!/bin/bash
+# Dev (GPU box): the Winograd stream-K modes (wino_streamk 1 = both directions, 2 = forward only, 0 = never) at the reference's default batch 64, interleaved.
 for r in 1 2 3; do for v in 1 2 0; do
 OSI_WINO_STREAMK=$v python bench.py --batch 64 --no-cpu-baseline --sustained-steps 0 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); pc=d['roofline']['per_class']
