@@ -463,11 +463,14 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumentation of the executor")
     ap.add_argument("--force-dp", action="store_true", help="dev: with one rank, still run the data-parallel step (staged backward + "
                     "RCCL bucket all-reduce on a world-1 communicator) to price the N>1 code path on a one-GPU box")
-    ap.add_argument("--sustained-steps", type=int, default=int(os.environ.get("OSI_BENCH_SUSTAINED", "600")),
-                    help="further steps AFTER the timed windows (never part of `value`), reported as `sustained` in 50-step windows; 0 = off")
+    ap.add_argument("--sustained-steps", type=int, default=None,
+                    help="further steps AFTER the timed windows (never part of `value`), reported as `sustained` in 50-step windows; 0 = off. "
+                         "Default 600 (OSI_BENCH_SUSTAINED), and 0 for dev runs (--no-profile or --windows 1: A/B and counter passes)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 self-launch: seconds before the ranks are terminated")
     ap.add_argument("--bind", default="auto", choices=("auto", "near", "even", "none"), help="N > 1 self-launch: CPU binding of the ranks")
     args = ap.parse_args()
+    if args.sustained_steps is None:
+        args.sustained_steps = 0 if (args.no_profile or args.windows == 1) else int(os.environ.get("OSI_BENCH_SUSTAINED", "600"))
     if args.windows < 1 or args.steps < 1 or args.warmup < 0 or args.cpus_per_gpu < 1 or args.sustained_steps < 0:
         ap.error("--windows, --steps and --cpus-per-gpu must be >= 1, --warmup and --sustained-steps >= 0")
 
@@ -538,14 +541,21 @@ def main():
         ch = rccl_channels(rccl_log)
         if os.environ.get("OSI_DP_RESERVED_CUS"):
             reserved = {"value": int(os.environ["OSI_DP_RESERVED_CUS"]), "source": "OSI_DP_RESERVED_CUS"}
-        elif ch["coll_channels"] is not None and world > 1:
-            v = torch.tensor([reserved_cus_for_channels(ch["coll_channels"])], device=dev, dtype=torch.int32)
+        elif world > 1:
+            # EVERY rank enters this collective, whatever its own log said (each rank parses its own INIT log; the "Channel xx/N" lines
+            # are rank 0's only and a log may not be flushed yet): a rank that knows nothing contributes -1, MAX over the ranks decides,
+            # and the knob is only touched when somebody knew. A collective some ranks skip would hang the ones that follow.
+            mine_cus = -1 if ch["coll_channels"] is None else reserved_cus_for_channels(ch["coll_channels"])
+            v = torch.tensor([mine_cus], device=dev, dtype=torch.int32)
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
-            N.check(N.lib().osi_set_tuning(b"dp_reserved_cus", int(v)))
-            reserved = {"value": int(v), "source": f"ceil({ch['coll_channels']} RCCL channels / 8 workgroup slots per CU), MAX over ranks"}
+            if int(v) >= 0:
+                N.check(N.lib().osi_set_tuning(b"dp_reserved_cus", int(v)))
+                reserved = {"value": int(v), "source": "ceil(RCCL channels / 8 workgroup slots per CU), MAX over ranks "
+                                                       f"(this rank's INIT log: {ch['coll_channels']} channels)"}
+            else:
+                reserved = {"value": 0, "source": "default (no rank's RCCL INIT log named a channel count)"}
         else:
-            reserved = {"value": 0, "source": "default (world 1: nothing is resident beside the backward)" if world == 1
-                        else "default (the RCCL INIT log named no channel count)"}
+            reserved = {"value": 0, "source": "default (world 1: nothing is resident beside the backward)"}
     opt = optim.Adam(model.parameters(), lr=1e-3)
     images, labels = synthetic_batch(B, C, wl["p_neg"], wl["loss"], dev, 42 + rank)
     if wl["loss"] == "garbage":

@@ -30,6 +30,7 @@
 //   EPI 1 input gradient, "in-block" fusion of osi_conv_dgrad_fused: dx = gate . acc with the gate recomputed from the producer's pre-BN
 //     tensor (fma(y0, scale0, shift0) > 0), and the per-64-pixel sums of g and g * xhat0 for the BatchNorm backward of that producer.
 #include "conv_common.h"
+#include <algorithm>
 #include <utility>
 
 using namespace osi_conv;
@@ -930,8 +931,13 @@ int backward_exclusive_cus() {
     return n < 8 ? 8 : n;
 }
 // persistent grid: one workgroup per CU the launch may use, a multiple of 8 (a workgroup's units keep its blockIdx % 8 = its XCD)
+// Never more than the hardware's CUs: the knob tail_cus may name a larger chip (it is a plan parameter of the direct kernels' tail split,
+// range-checked to 0 .. 4096 only), but a 512-register workgroup beyond the CU count would only queue behind the others — and the
+// stream-K slab (slab_bytes_of) is sized for the hardware's CUs: workgroup w writes slots 2 w and 2 w + 1.
 int wino_grid(bool backward) {
-    int cus = (backward ? backward_exclusive_cus() : chip_cus()) / 8 * 8;
+    int cus = backward ? backward_exclusive_cus() : chip_cus();
+    if (cus > hw_cus()) cus = hw_cus();
+    cus = cus / 8 * 8;
     return cus < 8 ? 8 : cus;
 }
 constexpr size_t SLOT_BYTES = 65536;      // one partial tile: 256 pixels x 64 channels, fp32
@@ -939,7 +945,7 @@ size_t u_bytes_of(const osi_conv_desc* d) { return ((size_t)16 * d->Cin * d->Cou
 size_t slab_bytes_of() { return (size_t)(hw_cus() / 8 * 8 < 8 ? 8 : hw_cus() / 8 * 8) * 2 * SLOT_BYTES; }
 
 // q full rounds + r remainder units over G workgroups; slab behind the transformed weights
-void plan_units(WinoP& p, void* slab, const osi_conv_desc* d, int G, bool input_gradient) {
+void plan_units(WinoP& p, void* slab, size_t slab_bytes, const osi_conv_desc* d, int G, bool input_gradient) {
     const int V = p.MT * p.NT;
     p.q = V / G; p.r = V - p.q * G; p.nfull = p.q * G;
     // short units (KS <= 4: the 64-channel layers) keep their ragged last round: a piece of one or two slices plus the fix-up pass costs
@@ -952,7 +958,9 @@ void plan_units(WinoP& p, void* slab, const osi_conv_desc* d, int G, bool input_
     const bool cut = sk == 1 || (sk == 2 && !input_gradient) || (sk == 3 && input_gradient);
     if (!cut || (p.KS <= 4 && !heavy_tail)) { p.nfull = V; p.r = 0; }
     p.slab = (float*)slab;
-    p.slab_bytes = (int)((size_t)G * 2 * SLOT_BYTES);
+    // the buffer range of the slab descriptor is what the caller really passed (callers require slab_bytes >= G * 2 * SLOT_BYTES): a store
+    // past it is dropped by the range check instead of landing in the neighbouring workspace
+    p.slab_bytes = (int)std::min<size_t>(slab_bytes, (size_t)hw_cus() * 2 * SLOT_BYTES);
 }
 
 }  // namespace
@@ -997,7 +1005,8 @@ static int fwd_wino_impl(const osi_conv_desc* d, const float* x, const float* in
     }
     if (w) { if (int e = launch_weights<0>(w, u, d->Cin, d->Cout, st)) return e; }
     const int G = wino_grid(false);
-    plan_units(p, slab, d, G, false);
+    OSI_REQUIRE(slab_bytes >= (size_t)G * 2 * SLOT_BYTES);
+    plan_units(p, slab, slab_bytes, d, G, false);
     const dim3 grid((unsigned)G), blk(256);
     const bool wide = wide_units(d->Cout), odd = g.odd || (wide && g.T % 32 != 0);
     auto launch = [&](auto XFC, auto ODDC, auto WIDEC) {
@@ -1070,7 +1079,8 @@ static int dgrad_wino_impl(const osi_conv_desc* d, const float* dy, const float*
     *P = g.P;
     if (w) { if (int e = launch_weights<1>(w, u, d->Cout, d->Cin, st)) return e; }
     const int G = wino_grid(true);
-    plan_units(p, slab, d, G, true);
+    OSI_REQUIRE(slab_bytes >= (size_t)G * 2 * SLOT_BYTES);
+    plan_units(p, slab, slab_bytes, d, G, true);
     const dim3 grid((unsigned)G), blk(256);
     const bool wide = wide_units(d->Cin), odd = g.odd || (wide && g.T % 32 != 0);
     auto launch = [&](auto ODDC, auto WIDEC) {

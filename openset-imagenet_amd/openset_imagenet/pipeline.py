@@ -106,17 +106,17 @@ class CanvasDataset(torch.utils.data.Dataset):
         return torch.from_numpy(np.array(x)).permute(2, 0, 1).float().div_(255.0), label   # ToTensor() on the host
 
 
-def worker_init(worker_id=0, niceness=10):
-    """DataLoader `worker_init_fn`: the decode workers run at a lower scheduling priority than the process that launches the GPU work.
-    On a lease of N CPUs per GPU the workers (N of them, bursty: they run ahead until the prefetch queues are full) otherwise compete
-    with the one thread whose latency the GPU sees — kernel launches queue up behind decode time slices and the step shows bubbles
-    (profiles/r05_input_pipeline.json: 0.91 -> see there of the synthetic rate at 16 workers on 16 CPUs). Also keeps every worker to one
-    intra-op thread."""
+def worker_init(worker_id=0, niceness=0):
+    """DataLoader `worker_init_fn` of worker(): every decode worker keeps to ONE intra-op thread (a worker process otherwise inherits
+    torch's default pool size — the host's CPU count — for its tensor ops, on a lease of 16 CPUs per GPU that it shares with 15 other
+    workers and the thread that launches the GPU work). `niceness` > 0 also lowers the workers' scheduling priority; measured on a
+    16-CPU lease it changes nothing (profiles/NOTES_r05.md: the launch thread is not starved by the workers), so the default leaves it."""
     import os
-    try:
-        os.nice(niceness)
-    except OSError:
-        pass
+    if niceness > 0:
+        try:
+            os.nice(niceness)
+        except OSError:
+            pass
     torch.set_num_threads(1)
 
 

@@ -298,7 +298,9 @@ def _worker_body(cfg, log, out_dir, rank, world, distributed):
         sub = 1
     lkw = dict(batch_size=cfg.batch_size // sub, num_workers=cfg.workers, pin_memory=True)
     if cfg.workers > 0:
-        lkw.update(persistent_workers=True, prefetch_factor=4 * sub)   # the same number of samples ahead per worker
+        from .pipeline import worker_init
+        lkw.update(persistent_workers=True, prefetch_factor=4 * sub,   # the same number of samples ahead per worker
+                   worker_init_fn=worker_init)                         # one intra-op thread per decode worker
     train_loader = torch.utils.data.DataLoader(train_ds, shuffle=sampler is None, sampler=sampler, **lkw)
     val_loader = torch.utils.data.DataLoader(val_ds, **lkw)
     if prefetch:

@@ -280,3 +280,34 @@ def test_pretransformed_weights_give_the_same_bits(cuda):
     N.check(L.osi_conv_wino_transform_weights(ctypes.byref(d), N.ptr(w), 1, N.ptr(u), ub, T.S()))
     N.check(L.osi_conv_dgrad_fused_wino_pre(ctypes.byref(d), N.ptr(x), N.ptr(u), N.ptr(yb), ctypes.byref(f), N.ptr(slab), sb, ctypes.byref(P), T.S()))
     assert torch.equal(ya, yb)
+
+
+def test_plan_cus_above_the_device_do_not_resize_the_persistent_grid(cuda):
+    """Knob tail_cus names the CU count the direct kernels' tail plan balances for (0 .. 4096, any chip); the Winograd kernels are one
+    workgroup per HARDWARE CU with two slab slots each, so a larger figure must neither grow their grid nor let a workgroup write past the
+    stream-K slab (osi_conv_wino_slab_bytes() is sized for the device's CUs). Same bits as the default plan, canary behind the slab intact."""
+    import osi_testlib as T
+    from openset_imagenet import _native as N
+    L = N.lib()
+    B, H, Cin, Cout = 16, 14, 128, 64                      # 13 units of 8 K slices: every unit is cut into stream-K pieces (slab in use)
+    g = _gen(cuda, "wino-cus")
+    d = N.ConvDesc.make(B, H, H, Cin, Cout, 3, 1, 1)
+    x = torch.randn(B, H, H, Cin, device=cuda, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device=cuda, generator=g) * 0.05
+    ub, sb = L.osi_conv_wino_weights_bytes(ctypes.byref(d)), L.osi_conv_wino_slab_bytes()
+    u = torch.empty(ub, dtype=torch.uint8, device=cuda)
+    N.check(L.osi_conv_wino_transform_weights(ctypes.byref(d), N.ptr(w), 0, N.ptr(u), ub, T.S()))
+    guard = 1 << 20
+    outs = []
+    try:
+        for cus in (0, 512, 4096):
+            N.check(L.osi_set_tuning(b"tail_cus", cus))
+            slab = torch.full((sb + guard,), 0xA5, dtype=torch.uint8, device=cuda)
+            y = torch.full((B, H, H, Cout), float("nan"), device=cuda)
+            N.check(L.osi_conv_fwd_wino_pre(ctypes.byref(d), N.ptr(x), None, None, N.ptr(u), N.ptr(y), N.ptr(slab), sb, None, 0, None, None, T.S()))
+            torch.cuda.synchronize()
+            assert bool((slab[sb:] == 0xA5).all()), f"tail_cus = {cus}: a workgroup wrote past the stream-K slab"
+            outs.append(y)
+    finally:
+        N.check(L.osi_set_tuning(b"tail_cus", 0))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/${1:-clock_in_step}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d "$OUT/pmc" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-profile > "$OUT/bench.json" 2> "$OUT/pmc.err"
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d "$OUT/pmc" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-profile --sustained-steps 0 > "$OUT/bench.json" 2> "$OUT/pmc.err"
 f=$(find "$OUT/pmc" -name "*counter_collection.csv" | head -1)
 python3 - "$f" > "$OUT/summary.txt" <<'PY'
 import csv, sys, collections

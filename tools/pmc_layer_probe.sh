@@ -4,7 +4,7 @@
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$1; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in $2; do
-  OSI_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --windows 1 --no-cpu-baseline --no-profile > "$OUT/bench_$c.json" 2> "$OUT/$c.err"
+  OSI_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --windows 1 --no-cpu-baseline --no-profile --sustained-steps 0 > "$OUT/bench_$c.json" 2> "$OUT/$c.err"
 done
 python3 - "$OUT" $2 <<'PY'
 import csv, sys, os, glob

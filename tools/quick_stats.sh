@@ -2,7 +2,7 @@
 # Dev tool (GPU box): per-kernel durations of a short serialized bench run; prints the top kernels. tools/quick_stats.sh <tag> [filter]
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$1; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-OSI_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d "$OUT" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --windows 1 --no-cpu-baseline --no-profile > "$OUT/bench.json" 2> "$OUT/err.txt"
+OSI_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d "$OUT" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --windows 1 --no-cpu-baseline --no-profile --sustained-steps 0 > "$OUT/bench.json" 2> "$OUT/err.txt"
 f=$(find "$OUT" -name "s_kernel_stats.csv" | head -1)
 python3 - "$f" "${2:-}" <<'PY'
 import csv, sys

@@ -16,7 +16,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_WAVES" \
            "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT"; do
   i=$((i+1))
-  OSI_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $set -d "$OUT/p$i" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --windows 1 --no-cpu-baseline --no-profile > "$OUT/bench_p$i.json" 2> "$OUT/p$i.err"
+  OSI_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $set -d "$OUT/p$i" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --windows 1 --no-cpu-baseline --no-profile --sustained-steps 0 > "$OUT/bench_p$i.json" 2> "$OUT/p$i.err"
   echo "pass $i ($set): rc=$?"
 done
 python3 "$ROOT/tools/stall_summary.py" "$OUT"
