@@ -130,6 +130,26 @@ int osi_conv_fwd_wino_pre(const osi_conv_desc* d, const float* x, const float* i
                           void* slab, size_t slab_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
 int osi_conv_fwd_wino(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
                       void* ws, size_t ws_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream);
+/* Inference forms (validate() / get_arrays(), openset_imagenet/train.py:142-234: model.eval(), BatchNorm on running statistics). In eval
+ * mode a BatchNorm's scale / shift are known before its convolution is launched, so the convolution's epilogue applies them — plus the
+ * Bottleneck's shortcut and ReLU (torchvision Bottleneck.forward under model.py:37) — and the pre-BN tensor is never written:
+ *     out = [relu](conv2d(x, w) * scale[n] + shift[n] [+ residual])          one fma, one add, one max per element
+ * (the roundings of osi_bn_apply: bit-identical to osi_conv_fwd followed by osi_bn_apply on the same accumulators). residual: same
+ * shape as out, may be NULL, must not alias out. ws: osi_conv_fwd_epilogue_workspace(d) bytes (slab of a K-split tail; may be 0 / NULL:
+ * the launch is then single-pass). Not for the stem (its tail is osi_bn_relu_maxpool_fwd). Cin % 32 == 0, Cout % 64 == 0. */
+typedef struct {
+    const float* scale;     /* [Cout], e.g. from osi_bn_eval_coeffs */
+    const float* shift;     /* [Cout] */
+    const float* residual;  /* [B][Ho][Wo][Cout] or NULL */
+    int relu;
+} osi_conv_epilogue;
+size_t osi_conv_fwd_epilogue_workspace(const osi_conv_desc* d);
+int osi_conv_fwd_epilogue(const osi_conv_desc* d, const float* x, const float* w, float* out, const osi_conv_epilogue* e, void* ws,
+                          size_t ws_bytes, osi_stream_t stream);
+/* The Winograd form of the same for the shapes osi_conv_wino_eligible(d, 0) takes; e->residual must be NULL (conv2 of a Bottleneck has
+ * no shortcut); u / slab as osi_conv_fwd_wino_pre. */
+int osi_conv_fwd_wino_epilogue_pre(const osi_conv_desc* d, const float* x, const float* u, float* out, const osi_conv_epilogue* e, void* slab,
+                                   size_t slab_bytes, osi_stream_t stream);
 /* dx (+)= conv2d_input_grad(dy, w). accumulate = 1 adds into dx (skip-connection sum); accumulate = 2 ("sparse", ABI 4) writes
  * only the input pixels some filter tap reaches and leaves every other element of dx UNTOUCHED (a stride-2 1x1 convolution reaches
  * the pixels with even h and even w: a quarter of the tensor) — for a consumer that knows the pattern, see
@@ -220,6 +240,14 @@ int osi_bn_finalize_stats(float* pstats, size_t pstats_bytes, int P, int rows_pe
 /* eval mode (validate(), train.py:142-196): scale/shift from the running statistics */
 int osi_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
                        int C, float* scale, float* shift, osi_stream_t stream);
+/* the same for up to OSI_BN_MULTI_MAX BatchNorm layers in one launch (the executor's inference forward: all 53 at once) */
+#define OSI_BN_MULTI_MAX 64
+typedef struct {
+    const float *running_mean, *running_var, *gamma, *beta;
+    float *scale, *shift;
+    int C;
+} osi_bn_eval_layer;
+int osi_bn_eval_coeffs_multi(const osi_bn_eval_layer* layers, int n, float eps, osi_stream_t stream);
 /* out = [relu](y*scale + shift [+ residual]) */
 int osi_bn_apply(const float* y, const float* residual, const float* scale, const float* shift, float* out, int M, int C,
                  int relu, osi_stream_t stream);
@@ -387,7 +415,10 @@ int osi_resnet50_set_overlap(osi_resnet50_t net, int enable);
  * stream, default 1), "fwd_recompute" (conv1 of a bottleneck recomputes the previous identity-shortcut block output in its loader and
  * that block's output pass runs beside it on the side stream; default 0: measured no faster), "side_priority_normal" (side stream at default instead of lowest priority; only before the first training
  * call, else OSI_ERR_STATE), "stage_join" (default 1; see osi_resnet50_grads_ready), "stagger", "stem_fused", "stem_pool_stats", "ds_sparse",
- * "stem_wgrad_main" (A/B switches of the backward schedule). Unknown name -> OSI_ERR_ARG. */
+ * "stem_wgrad_main" (A/B switches of the backward schedule), "eval_fused" (default 1: a forward with training = 0 runs
+ * the inference forms — every BatchNorm + shortcut + ReLU in its convolution's epilogue, no pre-BN tensor, no block-output pass, no
+ * bitmask, one coefficient launch for all 53 BatchNorms; 0 = the training topology on running statistics, kept for A/B; same bits).
+ * Unknown name -> OSI_ERR_ARG. */
 int osi_resnet50_set_option(osi_resnet50_t net, const char* name, int value);
 
 /* Optional HIP-event instrumentation of the executor (bench.py's roofline leg): one event after every op on the launch

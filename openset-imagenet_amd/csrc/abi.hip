@@ -41,7 +41,7 @@ int* tuning_slot(const char* name) {
 }  // namespace
 
 extern "C" {
-int osi_abi_version(void) { return 6; }   // 6: Winograd forms (osi_conv_*_wino), knobs "fwd_wino" / "dgrad_wino"; 5: osi_resnet50_grads_ready, executor option "stage_join", knob "dp_reserved_cus", range-checked knobs, plan snapshot (4: addend_stride, accumulate = 2)
+int osi_abi_version(void) { return 7; }   // 7: inference forms (osi_conv_fwd_epilogue, osi_conv_fwd_wino_epilogue_pre, osi_bn_eval_coeffs_multi), executor option "eval_fused"; 6: Winograd forms (osi_conv_*_wino), knobs "fwd_wino" / "dgrad_wino"; 5: osi_resnet50_grads_ready, executor option "stage_join", knob "dp_reserved_cus", range-checked knobs, plan snapshot (4: addend_stride, accumulate = 2)
 int osi_set_tuning(const char* name, int value) {
     int* s = tuning_slot(name);
     if (!s) return OSI_ERR_ARG;

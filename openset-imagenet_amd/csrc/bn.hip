@@ -292,6 +292,17 @@ __global__ void k_bn_eval_coeffs(const float* rm, const float* rv, const float* 
     scale[c] = sc; shift[c] = beta[c] - rm[c] * sc;
 }
 
+// the same for up to OSI_BN_MULTI_MAX layers in ONE launch (the inference forward of the executor: 53 BatchNorms, 53 tiny launches
+// otherwise): blockIdx.y = layer, the layer's six pointers ride in the kernel arguments
+struct BnEvalTable { osi_bn_eval_layer l[OSI_BN_MULTI_MAX]; };
+__global__ void k_bn_eval_coeffs_multi(BnEvalTable t, float eps) {
+    const osi_bn_eval_layer& L = t.l[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= L.C) return;
+    const float sc = L.gamma[c] * (1.0f / sqrtf(L.running_var[c] + eps));      // the expression of k_bn_eval_coeffs
+    L.scale[c] = sc; L.shift[c] = L.beta[c] - L.running_mean[c] * sc;
+}
+
 // ---- apply: out = [relu]( y*scale + shift [+ res] ) ---------------------------------------------------
 // ReLU bitmask: bit (i & 63) of word [(i >> 6) * 4 + c] = (component c of float4 #i is > 0 after BN(+res)). One bit per
 // element (1/32 of the tensor) lets both BatchNorm-backward passes skip re-reading the activation just to rebuild the mask.
@@ -630,6 +641,21 @@ int osi_bn_eval_coeffs(const float* running_mean, const float* running_var, cons
     OSI_REQUIRE(running_mean && running_var && gamma && beta && scale && shift && C > 0);
     hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(osi_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean, running_var,
                        gamma, beta, eps, C, scale, shift);
+    OSI_LAUNCH_CHECK();
+    return OSI_OK;
+}
+
+int osi_bn_eval_coeffs_multi(const osi_bn_eval_layer* layers, int n, float eps, osi_stream_t stream) {
+    OSI_REQUIRE(layers && n > 0 && n <= OSI_BN_MULTI_MAX);
+    BnEvalTable t{};
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const osi_bn_eval_layer& L = layers[i];
+        OSI_REQUIRE(L.running_mean && L.running_var && L.gamma && L.beta && L.scale && L.shift && L.C > 0);
+        t.l[i] = L;
+        if (L.C > cmax) cmax = L.C;
+    }
+    hipLaunchKernelGGL(k_bn_eval_coeffs_multi, dim3(osi_cdiv(cmax, 256), n), dim3(256), 0, (hipStream_t)stream, t, eps);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }

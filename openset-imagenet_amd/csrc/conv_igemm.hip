@@ -73,6 +73,12 @@ struct ConvP {
     const float* in_scale;
     const float* in_shift;
     const float* res;     // fwd XF = 2: shortcut tensor added before the ReLU (same shape as x)
+    // fwd OE (inference): the OUTPUT is [relu](fma(acc, osc[n], osh[n]) [+ ores[m][n]]) — the conv's own BatchNorm (eval-mode coefficients),
+    // the shortcut and the ReLU applied in the epilogue; the pre-BN tensor is never written.
+    const float* osc;
+    const float* osh;
+    const float* ores;    // [M][Cout] or NULL (read through a zero-record descriptor: no branch around the load)
+    int orelu;            // a select, not a branch
     size_t slab_stride;
     // fwd / dgrad, balanced remainder (see plan_tail_split): row tiles mt < MT1 are computed at full K by blocks [0, g1); the last
     // MT - MT1 row tiles are split ks_S ways along K by the blocks behind them, each writing its raw 64x64 accumulator tile to
@@ -236,9 +242,11 @@ __device__ __forceinline__ void mma_CC(const float* sA, const float* sB, int aco
 // vertical validity stays the loader's select — and the three K tiles run from it, the A fragment of a lane read at its own base row + s.
 // K-tile order (r, slice, s) instead of (r, s, slice). Activation rows loaded / transformed / stored per slice: 9 x 64 -> 3 x <= 78.
 constexpr int W3_WROWS = 78;   // 64 pixels + a pad slot per image row they cross (<= 64 / W + 1, W >= 7) + the two outer neighbours
-template <int WM, int WN, bool STEM, int NST, int XF = 0, bool KS = false, bool W3 = false>
+// OE (inference, plain input only): output epilogue [relu](fma(acc, osc, osh) [+ ores]) instead of the raw accumulators, see ConvP
+template <int WM, int WN, bool STEM, int NST, int XF = 0, bool KS = false, bool W3 = false, bool OE = false>
 __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM * WN >= 4 ? 3 : 4) : 2)) void k_conv_fwd(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
+    static_assert(!OE || (XF == 0 && !STEM && NST == 1), "output epilogue: the executor's single-buffered plain-input forms");
     static_assert(!W3 || (WM == 1 && WN == 1 && NST == 1 && !STEM && XF != 2), "row windows: the single-buffered 64x64 tile");
     constexpr int AROWS = W3 ? W3_WROWS : BM;      // rows of the A image in LDS
     constexpr int AR = W3 ? 3 : BM / 32, BR = BN / 32;  // float4 loads per thread per stage
@@ -503,6 +511,27 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
             for (int rr = 0; rr < 16; ++rr) smem[(wm * 32 + acc_row(rr, lane)) * LDT + wn * 32 + (lane & 31)] = acc[0][0][rr];
             __syncthreads();
             const int c4 = tid & 15, rg = tid >> 4;
+            if constexpr (OE) {
+                // the four rows' shortcut values first (all in flight together; no shortcut = zero records = zeros), then one fma, one
+                // add, one max per element: the roundings of k_bn_apply<RES = 1> (fma, add) and of the fused loaders (fma, max)
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.ores ? p.ores : p.y, p.ores ? p.M * p.Cout * 4 : 0);
+                const f32x4 sc = ld4(p.osc + n0 + c4 * 4), sh = ld4(p.osh + n0 + c4 * 4);
+                f32x4 rv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int m = m0 + rg + 16 * k;
+                    rv[k] = bld4(ro, m < p.M ? (uint32_t)((m * p.Cout + n0 + c4 * 4) * 4) : OOB, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int rl = rg + 16 * k, m = m0 + rl;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(smem + rl * LDT + c4 * 4);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float t = __builtin_fmaf(a[e], sc[e], sh[e]) + rv[k][e]; v[e] = p.orelu ? fmaxf(t, 0.f) : t; }
+                    if (m < p.M) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + c4 * 4) = v;
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int rl = rg + 16 * k, m = m0 + rl;
@@ -520,6 +549,22 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             const int col = n0 + wn * 32 * WN + n * 32 + (lane & 31);
+            if constexpr (OE) {
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.ores ? p.ores : p.y, p.ores ? p.M * p.Cout * 4 : 0);
+                const float sc = p.osc[col], sh = p.osh[col];
+                float rv[16];
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int m = m0 + wm * 32 * WM + i * 32 + acc_row(rr, lane);
+                    rv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro, m < p.M ? (uint32_t)((m * p.Cout + col) * 4) : OOB, 0, 0));
+                }
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int m = m0 + wm * 32 * WM + i * 32 + acc_row(rr, lane);
+                    const float t = __builtin_fmaf(acc[i][n][rr], sc, sh) + rv[rr];
+                    if (m < p.M) p.y[(size_t)m * p.Cout + col] = p.orelu ? fmaxf(t, 0.f) : t;
+                }
+            } else
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 int m = m0 + wm * 32 * WM + i * 32 + acc_row(rr, lane);
@@ -1562,8 +1607,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad3(ConvP p) {   // 72 accum
 // same rows at about the same time and three of four reads hit that L2. Epilogue as in k_conv_fwd (LDS transpose -> 16-byte
 // stores, BatchNorm (mean, M2) partials per row tile straight from the accumulators).
 // ======================================================================================================
-template <int KT, int XF>   // KT = Cin / 32 K tiles (2 or 4); XF = 1: the A operand is relu(x * in_scale[c] + in_shift[c])
+template <int KT, int XF, bool OE = false>   // KT = Cin / 32 K tiles (2 or 4); XF = 1: the A operand is relu(x * in_scale[c] + in_shift[c]); OE: output epilogue (ConvP)
 __global__ __launch_bounds__(256, 4) void k_conv1x1_rows(ConvP p, int walkers) {
+    static_assert(!OE || XF == 0, "output epilogue: plain input");
     constexpr int BN = 64, IMG = 64 * LDR, LDT = BN + 4;
     static_assert(64 * LDT <= KT * IMG, "the transposed output tile reuses the activation images");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1646,6 +1692,25 @@ __global__ __launch_bounds__(256, 4) void k_conv1x1_rows(ConvP p, int walkers) {
         {   // 16-byte stores of 4 consecutive channels per lane (measured against 4-byte stores straight from the accumulators, which
             // save two barriers per tile: 86 vs 82 TFLOP/s on 64->256 @56x56)
             const int c4 = tid & 15, rg = tid >> 4;
+            if constexpr (OE) {          // [relu](fma(acc, osc, osh) [+ ores]) as in k_conv_fwd
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.ores ? p.ores : p.y, p.ores ? p.M * p.Cout * 4 : 0);
+                const f32x4 sc = ld4(p.osc + n0 + c4 * 4), sh = ld4(p.osh + n0 + c4 * 4);
+                f32x4 rv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int m = m0 + rg + 16 * k;
+                    rv[k] = bld4(ro, m < p.M ? (uint32_t)((m * p.Cout + n0 + c4 * 4) * 4) : OOB, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int rl = rg + 16 * k, m = m0 + rl;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(sA + rl * LDT + c4 * 4);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float t = __builtin_fmaf(a[e], sc[e], sh[e]) + rv[k][e]; v[e] = p.orelu ? fmaxf(t, 0.f) : t; }
+                    if (m < p.M) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + c4 * 4) = v;
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int rl = rg + 16 * k, m = m0 + rl;
@@ -1714,6 +1779,20 @@ __global__ __launch_bounds__(256) void k_conv_fwd_tail_fixup(ConvP p) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] += t[j][k];
+    }
+    if (p.osc) {      // inference launch: the output epilogue [relu](fma(acc, osc, osh) [+ ores]) on the summed tile (as k_conv_fwd<OE>); no statistics
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.ores ? p.ores : p.y, p.ores ? p.M * p.Cout * 4 : 0);
+        const f32x4 sc = ld4(p.osc + n0 + c4 * 4), sh = ld4(p.osh + n0 + c4 * 4);
+        f32x4 rv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m0 + rg + 16 * k;
+            rv[k] = bld4(ro, m < p.M ? (uint32_t)((m * p.Cout + n0 + c4 * 4) * 4) : OOB, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = __builtin_fmaf(v[k][e], sc[e], sh[e]) + rv[k][e]; v[k][e] = p.orelu ? fmaxf(t, 0.f) : t; }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1895,7 +1974,7 @@ static TailPlan plan_tail_split(long MT, int NT, int T) {
 }
 static size_t tail_slab_floats(const TailPlan& t) { return t.S > 1 ? (size_t)t.tiles * t.S * 4096 : 0; }
 
-template <int XF, bool W3 = false>
+template <int XF, bool W3 = false, bool OE = false>
 static int launch_fwd_split(ConvP p, const TailPlan& tp, float* slab, hipStream_t st) {
     p.MT = osi_cdiv(p.M, 64); p.NT = p.Cout / 64;
     p.MT1 = tp.MT1; p.ks_S = tp.S; p.ks_T = tp.ksT; p.ks_slab = slab;
@@ -1905,37 +1984,37 @@ static int launch_fwd_split(ConvP p, const TailPlan& tp, float* slab, hipStream_
     size_t smem = (size_t)((W3 ? W3_WROWS : 64) + 64) * LDR * sizeof(float);
     if (XF) smem += (size_t)2 * p.Cin * sizeof(float);
     if (W3) p.cW[0] = make_fastdiv((uint32_t)p.W + 1);     // row windows: division by the padded row length
-    if (int e = set_smem(k_conv_fwd<1, 1, false, 1, XF, true, W3>, smem)) return e;
-    hipLaunchKernelGGL((k_conv_fwd<1, 1, false, 1, XF, true, W3>), dim3(grid), dim3(256), smem, st, p);
+    if (int e = set_smem(k_conv_fwd<1, 1, false, 1, XF, true, W3, OE>, smem)) return e;
+    hipLaunchKernelGGL((k_conv_fwd<1, 1, false, 1, XF, true, W3, OE>), dim3(grid), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_conv_fwd_tail_fixup, dim3(tp.tiles), dim3(256), 0, st, p);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
 
-template <int WM, int WN, bool STEM, int NST = 2, int XF = 0, bool W3 = false>
+template <int WM, int WN, bool STEM, int NST = 2, int XF = 0, bool W3 = false, bool OE = false>
 static int launch_fwd(ConvP p, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     p.MT = osi_cdiv(p.M, BM); p.NT = p.Cout / BN;
     size_t smem = NST * (size_t)((W3 ? W3_WROWS : BM) + BN) * LDR * sizeof(float);
     if (XF) smem += (size_t)2 * p.Cin * sizeof(float);
     if (W3) p.cW[0] = make_fastdiv((uint32_t)p.W + 1);     // row windows: division by the padded row length
-    if (int e = set_smem(k_conv_fwd<WM, WN, STEM, NST, XF, false, W3>, smem)) return e;
+    if (int e = set_smem(k_conv_fwd<WM, WN, STEM, NST, XF, false, W3, OE>, smem)) return e;
     int grid = osi_cdiv(p.MT, 8) * 8 * p.NT;
-    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM, NST, XF, false, W3>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((k_conv_fwd<WM, WN, STEM, NST, XF, false, W3, OE>), dim3(grid), dim3(256), smem, st, p);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
 // 1x1 stride-1 forward with Cin = 64 / 128 on the persistent row walker (k_conv1x1_rows): four resident workgroups per CU
-template <int KT, int XF>
+template <int KT, int XF, bool OE = false>
 static int launch_fwd_rows(ConvP p, hipStream_t st) {
     p.MT = osi_cdiv(p.M, 64); p.NT = p.Cout / 64;
     int walkers = (4 * hw_cus() / p.NT + 7) / 8 * 8;
     if (walkers < 8) walkers = 8;
     if (walkers > p.MT) walkers = (p.MT + 7) / 8 * 8;
     const size_t smem = ((size_t)2 * KT * 64 * LDR + 2 * p.Cin + 2 * 64 * 3) * sizeof(float);
-    if (int e = set_smem(k_conv1x1_rows<KT, XF>, smem)) return e;
-    hipLaunchKernelGGL((k_conv1x1_rows<KT, XF>), dim3(walkers * p.NT), dim3(256), smem, st, p, walkers);
+    if (int e = set_smem(k_conv1x1_rows<KT, XF, OE>, smem)) return e;
+    hipLaunchKernelGGL((k_conv1x1_rows<KT, XF, OE>), dim3(walkers * p.NT), dim3(256), smem, st, p, walkers);
     OSI_LAUNCH_CHECK();
     return OSI_OK;
 }
@@ -2299,6 +2378,36 @@ static int conv_fwd_impl(const osi_conv_desc* d, const float* x, const float* w,
         case OSI_TILE_128x64_S1: return launch_fwd<2, 1, false, 1>(p, st);
         default: return OSI_ERR_ARG;
     }
+}
+
+// ---- inference form: the convolution's own BatchNorm (eval coefficients), shortcut and ReLU in the epilogue --------------------------
+size_t osi_conv_fwd_epilogue_workspace(const osi_conv_desc* d) {
+    if (!desc_ok(d) || is_stem(d)) return 0;
+    return tail_slab_floats(fwd_tail_plan(d)) * sizeof(float);     // slab of a K-split tail; 0: the launch is single-pass
+}
+
+int osi_conv_fwd_epilogue(const osi_conv_desc* d, const float* x, const float* w, float* out, const osi_conv_epilogue* e, void* ws,
+                          size_t ws_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(desc_ok(d) && !is_stem(d) && x && w && out && e && e->scale && e->shift);
+    OSI_REQUIRE(d->Cin % BK == 0 && d->Cout % 64 == 0);
+    OSI_REQUIRE(e->residual != out);
+    hipStream_t st = (hipStream_t)stream;
+    ConvP p = make_p(d);
+    p.x = x; p.w = w; p.y = out; p.accumulate = 0;
+    p.osc = e->scale; p.osh = e->shift; p.ores = e->residual; p.orelu = e->relu ? 1 : 0;
+    p.unit = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) ? 1 : 0;
+    p.x_bytes = (int)((size_t)d->B * d->H * d->W * d->Cin * 4);
+    p.w_bytes = (int)((size_t)d->Cout * p.Ktot * 4);
+    // the same launch plans as the training forward (conv_fwd_impl with OSI_TILE_AUTO): row walker, row windows, K-split tail, tile rule
+    if (rows_rule(d, p.unit != 0, nullptr)) return d->Cin == 64 ? launch_fwd_rows<2, 0, true>(p, st) : launch_fwd_rows<4, 0, true>(p, st);
+    const bool w3 = g_osi_tuning.fwd_w3 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->W >= 7 && d->H == d->Ho && d->W == d->Wo;
+    const TailPlan tp = fwd_tail_plan(d);
+    if (tp.S > 1 && ws && ws_bytes >= tail_slab_floats(tp) * sizeof(float))
+        return w3 ? launch_fwd_split<0, true, true>(p, tp, (float*)ws, st) : launch_fwd_split<0, false, true>(p, tp, (float*)ws, st);
+    if (w3) return launch_fwd<1, 1, false, 1, 0, true, true>(p, st);
+    const long tiles64 = ((long)p.M + 63) / 64 * (d->Cout / 64);
+    if (d->Cout % 128 == 0 && (tiles64 < 1024 || g_osi_tuning.fwd_wide)) return launch_fwd<1, 2, false, 1, 0, false, true>(p, st);
+    return launch_fwd<1, 1, false, 1, 0, false, true>(p, st);
 }
 
 static bool dgrad_w3(const osi_conv_desc* d) {

@@ -75,6 +75,9 @@ struct WinoP {
     const float* ey0;    // producer's pre-BN tensor, same shape as y
     const float *escale0, *eshift0, *emean0, *einv0;
     float* esum;         // [3][P][Nc]: sum g, sum g * xhat0 (third plane unused)
+    // forward, inference epilogue (EPI 2): y = [relu](fma(acc, osc[n], osh[n])) — the conv's own BatchNorm (eval coefficients) + ReLU
+    const float *osc, *osh;
+    int orelu;
     // work decomposition: q full rounds of whole units, r remainder units cut along K into G pieces (slab: 2 slots of 64 KiB per workgroup)
     int q, r, nfull;
     float* slab;
@@ -235,6 +238,19 @@ __device__ __forceinline__ void epi0_quad(const WinoP& p, PUT put, int g, f32x4 
     }
 }
 
+// Inference epilogue of one channel quad: the convolution's own BatchNorm (eval-mode scale / shift) and ReLU on the way out — one fma and
+// one max per element, the expression the fused loaders evaluate on the consumer side in training (osi_conv_fwd_act)
+template <class PUT>
+__device__ __forceinline__ void epi2_quad(const WinoP& p, PUT put, int g, const f32x4 (&o)[4], const f32x4& sc, const f32x4& sh) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = __builtin_fmaf(o[k][e], sc[e], sh[e]); v[e] = p.orelu ? fmaxf(t, 0.f) : t; }
+        put(k, g, v);
+    }
+}
+
 // Operands of the input-gradient epilogue of one channel quad: the producer's pre-BN values at this lane's four pixels and the per-channel
 // gate / xhat coefficients. Loaded one quad AHEAD of their use (k_wino) — a lone wave per SIMD has nothing else to cover the round trip.
 struct Epi1Ops { f32x4 y0[4], esc, esh, emu, einv; };
@@ -290,7 +306,8 @@ __device__ __forceinline__ void out_offsets(const WinoP& p, int mt, int nt, int 
         }
 }
 
-// XF: fused input activation. EPI: 0 forward (+ statistics when p.pmean), 1 input gradient with the in-block fused epilogue.
+// XF: fused input activation. EPI: 0 forward (+ statistics when p.pmean), 1 input gradient with the in-block fused epilogue, 2 forward with
+// the inference epilogue (own BatchNorm + ReLU applied to the output).
 // ODD: some tile slots hold pixels outside the image (odd H / W) or past the last tile — their outputs are masked out of the sums.
 // WIDE: the unit is 32 tiles x 128 channels instead of 64 x 64 — the four waves own the four 32-channel blocks of the SAME 32 tiles, so a
 // tile's patch transform (the VALU work fp32 MFMAs cannot hide) serves twice as many channels: every thread transforms a (tile, channel
@@ -529,6 +546,7 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
 #endif
                 };
                 if constexpr (EPI == 0) epi0_quad<ODD>(p, put, g, o, po, ch0, part, lane);
+                else if constexpr (EPI == 2) epi2_quad(p, put, g, o, ld4(p.osc + ch0 + 8 * g), ld4(p.osh + ch0 + 8 * g));
                 else {
                     const Epi1Ops Ln = epi1_load(p, r0y, g < 3 ? g + 1 : 3, po, ch0);      // the next quad's operands behind this quad's arithmetic
                     epi1_apply<ODD>(p, put, g, o, po, ch0, part, lane, L1);
@@ -594,6 +612,7 @@ __global__ __launch_bounds__(64) void k_wino_fixup(WinoP p, int G) {
     const int ch0 = (WIDE ? 128 : 64) * nt + 32 * wm + 4 * hh, part = mt * (WIDE ? 2 : 4) + 2 * wn + ((lane >> 4) & 1);
     auto put = [&](int k, int gq, const f32x4& v) { bst4(ry, v, po[k] == OOB ? OOB : po[k] + 32u * gq, 0); };
     if constexpr (EPI == 0) epi0_quad<ODD>(p, put, g, o, po, ch0, part, lane);
+    else if constexpr (EPI == 2) epi2_quad(p, put, g, o, ld4(p.osc + ch0 + 8 * g), ld4(p.osh + ch0 + 8 * g));
     else {
         const Epi1Ops L = epi1_load(p, make_rsrc(p.ey0, p.y_bytes), g, po, ch0);
         epi1_apply<ODD>(p, put, g, o, po, ch0, part, lane, L);
@@ -989,8 +1008,9 @@ size_t osi_conv_wino_workspace(const osi_conv_desc* d) {
 // w != NULL: transformed into `u` first; w == NULL: `u` already holds this convolution's transformed weights (osi_conv_wino_transform_weights)
 static int fwd_wino_impl(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* w, float* u,
                          float* y, void* slab, size_t slab_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block,
-                         osi_stream_t stream) {
+                         osi_stream_t stream, const osi_conv_epilogue* epi = nullptr) {
     OSI_REQUIRE(x && u && y && slab && osi_conv_wino_eligible(d, 0));
+    OSI_REQUIRE(!epi || (epi->scale && epi->shift && !epi->residual && !in_scale && !pstats));
     OSI_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
     OSI_REQUIRE(slab_bytes >= slab_bytes_of());
     OSI_REQUIRE(!pstats || (P && rows_per_block));
@@ -998,6 +1018,7 @@ static int fwd_wino_impl(const osi_conv_desc* d, const float* x, const float* in
     const Geo g = geo_of(d);
     WinoP p = make_wp(d, g, d->Cin, d->Cout);
     p.x = x; p.u = u; p.y = y; p.sc = in_scale; p.sh = in_shift;
+    if (epi) { p.osc = epi->scale; p.osh = epi->shift; p.orelu = epi->relu ? 1 : 0; }
     if (pstats) {
         OSI_REQUIRE(pstats_bytes >= (size_t)2 * g.P * d->Cout * sizeof(float));
         p.pmean = pstats; p.pm2 = pstats + (size_t)g.P * d->Cout;
@@ -1019,7 +1040,21 @@ static int fwd_wino_impl(const osi_conv_desc* d, const float* x, const float* in
         }
         return OSI_OK;
     };
+    auto launch_epi = [&](auto ODDC, auto WIDEC) {       // inference epilogue: plain input, own BatchNorm + ReLU on the output
+        constexpr bool od = decltype(ODDC)::value, wd = decltype(WIDEC)::value;
+        hipLaunchKernelGGL((k_wino<false, 2, od, wd>), grid, blk, 0, st, p);
+        if (hipGetLastError() != hipSuccess) return OSI_ERR_LAUNCH;
+        if (p.r > 0) {
+            hipLaunchKernelGGL((k_wino_fixup<2, od, wd>), dim3((unsigned)p.r * 16), dim3(64), 0, st, p, G);
+            if (hipGetLastError() != hipSuccess) return OSI_ERR_LAUNCH;
+        }
+        return OSI_OK;
+    };
     using T_ = std::true_type; using F_ = std::false_type;
+    if (epi) {
+        if (odd) return wide ? launch_epi(T_{}, T_{}) : launch_epi(T_{}, F_{});
+        return wide ? launch_epi(F_{}, T_{}) : launch_epi(F_{}, F_{});
+    }
     const int sel = (in_scale ? 4 : 0) | (odd ? 2 : 0) | (wide ? 1 : 0);
     switch (sel) {
         case 0: return launch(F_{}, F_{}, F_{});
@@ -1054,6 +1089,14 @@ int osi_conv_wino_transform_weights(const osi_conv_desc* d, const float* w, int 
 int osi_conv_fwd_wino_pre(const osi_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, const float* u, float* y,
                           void* slab, size_t slab_bytes, float* pstats, size_t pstats_bytes, int* P, int* rows_per_block, osi_stream_t stream) {
     return fwd_wino_impl(d, x, in_scale, in_shift, nullptr, const_cast<float*>(u), y, slab, slab_bytes, pstats, pstats_bytes, P, rows_per_block, stream);
+}
+
+/* Winograd twin of osi_conv_fwd_epilogue (no shortcut: conv2 of a bottleneck has none): out = [relu](conv2d(x, w) * scale[n] + shift[n]),
+ * weights already transformed (osi_conv_wino_transform_weights). Eligible shapes as the forward form (osi_conv_wino_eligible(d, 0)). */
+int osi_conv_fwd_wino_epilogue_pre(const osi_conv_desc* d, const float* x, const float* u, float* out, const osi_conv_epilogue* e, void* slab,
+                                   size_t slab_bytes, osi_stream_t stream) {
+    OSI_REQUIRE(e);
+    return fwd_wino_impl(d, x, nullptr, nullptr, nullptr, const_cast<float*>(u), out, slab, slab_bytes, nullptr, 0, nullptr, nullptr, stream, e);
 }
 
 /* Winograd twin of osi_conv_dgrad_fused for the executor's "in-block" fusion only: no addend, no stored bitmask, one consumer, no pool

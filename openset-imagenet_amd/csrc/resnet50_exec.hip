@@ -91,7 +91,8 @@ struct osi_resnet50 {
     size_t stage_lo[4], stage_hi[4];
     // run state
     bool fwd_done = false;
-    bool any_fwd = false;            // some forward has run on this executor (osi_resnet50_debug_gate refuses to read an empty workspace)
+    bool any_fwd = false;            // the workspace holds the ReLU / arg-max decisions of a forward (osi_resnet50_debug_gate refuses to read an
+                                     // empty workspace — or one an inference forward ran in: that one stores activations, not pre-BN tensors or bitmasks)
     int next_stage = 0;
     int cur_grad = -1;               // scratch index holding the upstream gradient between stages
     bool go_fused = false;           // cur_grad is already ReLU-masked and its BatchNorm reductions wait in dg_ws
@@ -186,6 +187,8 @@ struct osi_resnet50 {
 #else
     static constexpr int dbg_skip = 0;
 #endif
+    bool eval_fused = true;          // option "eval_fused": a forward with training = 0 runs the inference forms (forward_eval_fused); 0 = the
+                                     // training topology on running statistics (A/B, same bits)
     bool stage_join = true;          // option "stage_join": a staged backward call (stage_hi < stages) ends by joining the side stream into
                                      // the caller's stream. 0 (data parallel): only the LAST stage joins; the caller hands each finished
                                      // stage to its communication stream with osi_resnet50_grads_ready, and the compute stream runs on
@@ -497,6 +500,102 @@ int osi_resnet50_bind_input_nhwc4(osi_resnet50_t n, const float* x_nhwc4) {
     return OSI_OK;
 }
 
+// avgpool -> fc -> logits, copies to the caller's tensors
+static int head_fwd(osi_resnet50* n, const float* params, float* ws, float* logits, float* features, hipStream_t st) {
+    const float* last = ws + n->blocks.back().out;
+    OSI_TRY(osi_avgpool_fwd(last, ws + n->pooled, n->B, n->Hf * n->Wf, 2048, st));
+    const Tensor& fw = n->tensors[n->t_fc_w]; const Tensor& fb = n->tensors[n->t_fc_b]; const Tensor& lw = n->tensors[n->t_lg_w];
+    OSI_TRY(osi_linear_fwd(ws + n->pooled, params + fw.off, params + fb.off, ws + n->feat, n->B, 2048, n->F, st));
+    const float* lb = n->t_lg_b >= 0 ? params + n->tensors[n->t_lg_b].off : nullptr;
+    OSI_TRY(osi_linear_fwd(ws + n->feat, params + lw.off, lb, ws + n->logits_ws, n->B, n->F, n->O, st));
+    if (hipMemcpyAsync(features, ws + n->feat, (size_t)n->B * n->F * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return OSI_ERR_LAUNCH;
+    if (hipMemcpyAsync(logits, ws + n->logits_ws, (size_t)n->B * n->O * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return OSI_ERR_LAUNCH;
+    return OSI_OK;
+}
+
+// Inference forward (training == 0; validate() / get_arrays(), reference train.py:142-234: model.eval() under no_grad). In eval mode
+// every BatchNorm's scale / shift exist before its convolution is launched, so nothing of the training topology's bookkeeping is
+// needed: ONE launch computes the coefficients of all 53 BatchNorms, and every convolution applies its own BatchNorm in its epilogue —
+// conv1 / conv2 write relu(bn(conv)), the projection shortcut writes bn(conv), conv3 writes the block output relu(bn3(conv3) + shortcut)
+// (osi_conv_fwd_epilogue / osi_conv_fwd_wino_epilogue_pre). No pre-BN tensor, no block-output pass, no ReLU bitmask, no fused-loader
+// activation on the consumer side (every consumer reads a finished activation with its plain loader): 53 + 16 + 53 launches fewer, the 16
+// HBM-bound block-output passes and the loader-side activation arithmetic gone. Values: the same fmas on the same accumulators as the
+// training topology on running statistics (option eval_fused = 0) — bit-identical outputs.
+// Buffers: conv1 / conv2 / shortcut activations live where the training forward keeps those layers' pre-BN tensors, the block outputs
+// where it keeps them; the workspace then holds no backward state (fwd_done and any_fwd are cleared).
+static int forward_eval_fused(osi_resnet50* n, const float* params, const float* buffers, float* ws, const float* x4, float* logits,
+                              float* features, hipStream_t st) {
+    {
+        osi_bn_eval_layer tab[OSI_BN_MULTI_MAX];
+        const int nb = (int)n->bns.size();
+        if (nb > OSI_BN_MULTI_MAX) return OSI_ERR_STATE;
+        for (int j = 0; j < nb; ++j) {
+            const BN& b = n->bns[j];
+            tab[j] = osi_bn_eval_layer{buffers + b.rm_off, buffers + b.rv_off, params + b.g_off, params + b.b_off, ws + b.scale, ws + b.shift, b.C};
+        }
+        OSI_TRY(osi_bn_eval_coeffs_multi(tab, nb, 1e-5f, st));
+        OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
+    }
+    Conv& c0 = n->convs[0];
+    OSI_TRY(osi_conv_fwd(&c0.d, x4, ws + n->wpack, ws + c0.y, OSI_TILE_AUTO, st));
+    OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
+    BN& b0 = n->bns[c0.bn];
+    OSI_TRY(osi_bn_relu_maxpool_fwd(ws + c0.y, ws + b0.scale, ws + b0.shift, ws + n->a_pool, ws + n->pool_idx, n->B, n->Hs, n->Ws, 64, st));
+    OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
+    auto epi = [&](int ci, const float* res, int relu) {
+        const BN& b = n->bns[n->convs[ci].bn];
+        return osi_conv_epilogue{ws + b.scale, ws + b.shift, res, relu};
+    };
+    for (Block& k : n->blocks) {
+        const float* x = ws + k.x_in;
+        Conv &c1 = n->convs[k.c1], &c2 = n->convs[k.c2], &c3 = n->convs[k.c3];
+        const bool fork = k.ds >= 0 && n->fwd_fork && n->async_wgrad();
+        if (k.ds >= 0) {            // the projection shortcut only depends on the block input: beside the main branch where a side stream exists
+            Conv& cd = n->convs[k.ds];
+            hipStream_t ds_st = st;
+            if (fork) {
+                if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
+                if (hipStreamWaitEvent(n->side, n->ev_fork, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+                ds_st = n->side;
+            }
+            const osi_conv_epilogue e = epi(k.ds, nullptr, 0);
+            OSI_TRY(osi_conv_fwd_epilogue(&cd.d, x, params + cd.w_off, ws + cd.y, &e, ws + (fork ? n->bn_ws2 : n->bn_ws), n->bn_ws_bytes, ds_st));
+            OSI_TRY(n->mark(OSI_PROF_CONV_FWD, ds_st));
+            if (fork && hipEventRecord(n->ev_join, n->side) != hipSuccess) return OSI_ERR_LAUNCH;
+        }
+        {
+            const osi_conv_epilogue e = epi(k.c1, nullptr, 1);
+            OSI_TRY(osi_conv_fwd_epilogue(&c1.d, x, params + c1.w_off, ws + c1.y, &e, ws + n->bn_ws, n->bn_ws_bytes, st));
+            OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
+        }
+        {
+            const osi_conv_epilogue e = epi(k.c2, nullptr, 1);
+            if (n->plan_knobs.fwd_wino && c2.u_fw != (size_t)-1) {     // 3x3 / stride 1: Winograd F(2x2,3x3)
+                if (n->wt_pending) {      // the transformed weights come from the side stream
+                    if (hipStreamWaitEvent(st, n->ev_wt, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+                    n->wt_pending = false;
+                }
+                OSI_TRY(osi_conv_fwd_wino_epilogue_pre(&c2.d, ws + c1.y, ws + c2.u_fw, ws + c2.y, &e, ws + n->wino_ws, n->wino_ws_bytes, st));
+            } else {
+                OSI_TRY(osi_conv_fwd_epilogue(&c2.d, ws + c1.y, params + c2.w_off, ws + c2.y, &e, ws + n->bn_ws, n->bn_ws_bytes, st));
+            }
+            OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
+        }
+        if (fork && hipStreamWaitEvent(st, n->ev_join, 0) != hipSuccess) return OSI_ERR_LAUNCH;
+        {
+            const osi_conv_epilogue e = epi(k.c3, k.ds >= 0 ? ws + n->convs[k.ds].y : x, 1);
+            OSI_TRY(osi_conv_fwd_epilogue(&c3.d, ws + c2.y, params + c3.w_off, ws + c3.a, &e, ws + n->bn_ws, n->bn_ws_bytes, st));
+            OSI_TRY(n->mark(OSI_PROF_CONV_FWD, st));
+        }
+    }
+    OSI_TRY(head_fwd(n, params, ws, logits, features, st));
+    n->any_fwd = false;           // no pre-BN tensors, bitmasks or arg-max decisions of a training forward remain (osi_resnet50_debug_gate)
+    OSI_TRY(n->mark(OSI_PROF_OTHER, st));
+    return OSI_OK;
+}
+
 int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, long long* nbt, const float* image,
                          void* workspace, float* logits, float* features, int training, osi_stream_t stream) {
     OSI_REQUIRE(n && params && buffers && workspace && logits && features);
@@ -543,6 +642,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     Conv& c0 = n->convs[0];
     OSI_TRY(osi_stem_weight_pack(params + c0.w_off, ws + n->wpack, 64, st));
     OSI_TRY(n->mark(OSI_PROF_OTHER, st));
+    if (!training && n->eval_fused) return forward_eval_fused(n, params, buffers, ws, x4, logits, features, st);
     OSI_TRY(conv_bn_fwd(n, 0, params, buffers, ws, x4, ws + n->wpack, training, st, n->bn_ws));
     BN& b0 = n->bns[c0.bn];
     // bn1 + relu + maxpool in one pass: the 112x112x64 post-ReLU tensor is never materialised
@@ -606,17 +706,7 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
         }
         OSI_TRY(n->mark(OSI_PROF_BN_FWD, st));
     }
-    // head
-    const float* last = ws + n->blocks.back().out;
-    OSI_TRY(osi_avgpool_fwd(last, ws + n->pooled, n->B, n->Hf * n->Wf, 2048, st));
-    const Tensor& fw = n->tensors[n->t_fc_w]; const Tensor& fb = n->tensors[n->t_fc_b]; const Tensor& lw = n->tensors[n->t_lg_w];
-    OSI_TRY(osi_linear_fwd(ws + n->pooled, params + fw.off, params + fb.off, ws + n->feat, n->B, 2048, n->F, st));
-    const float* lb = n->t_lg_b >= 0 ? params + n->tensors[n->t_lg_b].off : nullptr;
-    OSI_TRY(osi_linear_fwd(ws + n->feat, params + lw.off, lb, ws + n->logits_ws, n->B, n->F, n->O, st));
-    if (hipMemcpyAsync(features, ws + n->feat, (size_t)n->B * n->F * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return OSI_ERR_LAUNCH;
-    if (hipMemcpyAsync(logits, ws + n->logits_ws, (size_t)n->B * n->O * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return OSI_ERR_LAUNCH;
+    OSI_TRY(head_fwd(n, params, ws, logits, features, st));
     n->any_fwd = true;
     if (training) {
         OSI_TRY(osi_i64_add(nbt, (int)n->bns.size(), 1, st));
@@ -1102,6 +1192,7 @@ int osi_resnet50_set_option(osi_resnet50_t n, const char* name, int value) {
     else if (!strcmp(name, "ds_sparse")) n->ds_sparse = value != 0;
     else if (!strcmp(name, "stem_wgrad_main")) n->stem_wgrad_main = value != 0;
     else if (!strcmp(name, "stage_join")) n->stage_join = value != 0;
+    else if (!strcmp(name, "eval_fused")) n->eval_fused = value != 0;
     else if (!strcmp(name, "wino_weights_aside")) n->wt_aside = value != 0;
 #ifdef OSI_DIAG
     else if (!strcmp(name, "dbg_skip")) n->dbg_skip = value;

@@ -28,6 +28,17 @@ class ConvDesc(Structure):
         return cls(B, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad)
 
 
+class ConvEpilogue(Structure):
+    """osi_conv_epilogue: out = [relu](conv * scale[n] + shift[n] [+ residual])"""
+    _fields_ = [("scale", c_void_p), ("shift", c_void_p), ("residual", c_void_p), ("relu", c_int)]
+
+
+class BnEvalLayer(Structure):
+    """osi_bn_eval_layer"""
+    _fields_ = [("running_mean", c_void_p), ("running_var", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("scale", c_void_p),
+                ("shift", c_void_p), ("C", c_int)]
+
+
 P = c_void_p
 _PD = POINTER(ConvDesc)
 
@@ -41,6 +52,10 @@ _SIGS = {
     "osi_conv_fwd": (c_int, [_PD, P, P, P, c_int, P]),
     "osi_conv_fwd_act": (c_int, [_PD, P, P, P, P, P, c_int, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
     "osi_conv_fwd_act2": (c_int, [_PD, P, P, P, P, P, P, c_int, P, c_size_t, POINTER(c_int), POINTER(c_int), P]),
+    "osi_conv_fwd_epilogue_workspace": (c_size_t, [_PD]),
+    "osi_conv_fwd_epilogue": (c_int, [_PD, P, P, P, POINTER(ConvEpilogue), P, c_size_t, P]),
+    "osi_conv_fwd_wino_epilogue_pre": (c_int, [_PD, P, P, P, POINTER(ConvEpilogue), P, c_size_t, P]),
+    "osi_bn_eval_coeffs_multi": (c_int, [POINTER(BnEvalLayer), c_int, c_float, P]),
     "osi_conv_wgrad_act": (c_int, [_PD, P, P, P, P, P, P, c_size_t, P]),
     "osi_conv_wino_eligible": (c_int, [_PD, c_int]),
     "osi_conv_wino_workspace": (c_size_t, [_PD]),

@@ -121,15 +121,68 @@ def train(model, data_loader, optimizer, loss_fn, trackers, cfg):
             trackers["j"].update(value, n)
 
 
-def validate(model, data_loader, loss_fn, n_classes, trackers, cfg):
+class ShardedEvalBatches(torch.utils.data.Sampler):
+    """`batch_sampler` of the validation loader under data parallel. The reference's validation loader is
+    `DataLoader(val_dataset, batch_size=cfg.batch_size)` (train.py:306-311): unshuffled, batch k = samples [k B, (k + 1) B), a ragged
+    last batch kept. This sampler yields exactly those batches — but only the ones with k % world == rank, each cut into `sub`
+    consecutive sub-batches of B / sub samples (what DevicePrefetcher(group=sub) reassembles; sub = 1: the batch itself). Whole
+    batches stay whole, so every per-batch loss is the value the single-process loop computes for that batch."""
+
+    def __init__(self, n_samples, batch_size, rank=0, world=1, sub=1):
+        if batch_size < 1 or world < 1 or not 0 <= rank < world or sub < 1 or batch_size % sub:
+            raise ValueError("ShardedEvalBatches: batch_size >= 1, 0 <= rank < world, batch_size % sub == 0")
+        self.n, self.B, self.rank, self.world, self.step = int(n_samples), int(batch_size), int(rank), int(world), int(batch_size) // int(sub)
+
+    def batches(self):
+        """global indices of this rank's batches"""
+        return range(self.rank, -(-self.n // self.B), self.world)
+
+    def __iter__(self):
+        for k in self.batches():
+            lo, hi = k * self.B, min(self.n, (k + 1) * self.B)
+            for s0 in range(lo, hi, self.step):
+                yield list(range(s0, min(hi, s0 + self.step)))
+
+    def __len__(self):
+        return sum(-(-(min(self.n, (k + 1) * self.B) - k * self.B) // self.step) for k in self.batches())
+
+
+def _confidence_partial(logits, labels, min_unk_score, unknown_class, last_valid, row):
+    """row (double[4], zero) += {sum known score[y], #known, sum negatives (1 + offset - max score[:last_valid]), #negatives} of ONE
+    batch: softmax + metrics.confidence (reference train.py:177, metrics.py:8-42) as one kernel, nothing synchronised."""
+    from . import _native as N
+    N.ops().confidence_accumulate(logits.contiguous(), labels.contiguous(), float(min_unk_score), int(unknown_class), int(last_valid), row)
+
+
+def _broadcast_buffers(model, group=None):
+    """BatchNorm running statistics of rank 0 on every rank (torch DDP's broadcast_buffers): the ranks normalise with their own batch
+    statistics while training, so their running statistics drift apart; validation must score ONE model — the one rank 0 checkpoints."""
+    import torch.distributed as dist
+    m = _unwrap(model)
+    if hasattr(m, "_flat_buffers"):
+        dist.broadcast(m._flat_buffers, src=0, group=group)
+        dist.broadcast(m._nbt, src=0, group=group)
+    else:
+        for b in m.buffers():
+            dist.broadcast(b, src=0, group=group)
+
+
+def validate(model, data_loader, loss_fn, n_classes, trackers, cfg, shard=None):
     """Validation loop with the reference's contract (train.py:142-196): eval-mode forward under no_grad, loss per batch into
     trackers["j"], known / negative confidences into trackers["conf_kn"] / ["conf_unk"].
 
     The reference fills an [N_val, C] softmax matrix on the device and reduces it with metrics.confidence() in Python loops
-    (`sum(known)`, metrics.py:27-28). Here softmax + confidence are one kernel per batch that accumulates the four sums in a
-    double[4] on the device (osi_confidence_accumulate); nothing is synchronised until the end of the loop."""
-    from . import _native as N
-    from .pipeline import device_batch
+    (`sum(known)`, metrics.py:27-28). Here softmax + confidence are one kernel per batch that leaves the batch's four sums in a
+    double[4] on the device; nothing is synchronised until the end of the loop, where the per-batch values are folded on the host in
+    batch order — the very sequence of `update()` calls and additions the reference performs.
+
+    `shard = (rank, world)` or `(rank, world, process_group)` (new — a departure from the reference's "Validate only on first
+    process", train.py:248, which leaves world - 1 GPUs idle for a quarter of every epoch's samples, protocol.py:245-250): the loader
+    yields only the batches rank, rank + world, ... of the unsharded, unshuffled batch sequence (ShardedEvalBatches); rank 0's BatchNorm
+    buffers are broadcast first, every rank evaluates its batches, the per-batch (index, loss, count, confidence sums) records are
+    all-gathered and EVERY rank replays them in batch order. The trackers are then bit-identical on all ranks to what a single
+    process computes on the whole loader: whole batches, the same kernels, the same order of additions. A rank that fails reports
+    its error through the same collective, so that no rank is left waiting: every rank raises."""
     for metric in trackers.values():
         metric.reset()
     if cfg.loss.type == "garbage":
@@ -137,25 +190,58 @@ def validate(model, data_loader, loss_fn, n_classes, trackers, cfg):
     else:
         min_unk_score, unknown_class, last_valid = 1.0 / n_classes, -1, 0   # 0 encodes Python's None (all columns)
     wants_features = isinstance(loss_fn, _losses.ObjectosphereLoss)
+    rank, world, group = 0, 1, None
+    if shard is not None:
+        rank, world = int(shard[0]), int(shard[1])
+        group = shard[2] if len(shard) > 2 else None
     model.eval()
-    losses, counts = [], []
-    acc = None
-    with torch.no_grad():
-        for batch in data_loader:
-            images, labels = device_batch(batch)
-            logits, features = model(images)
-            j = loss_fn(logits, labels, features) if wants_features else loss_fn(logits, labels)
-            losses.append(j)
-            counts.append(labels.shape[0])
-            if acc is None:
-                acc = torch.zeros(4, dtype=torch.float64, device=logits.device)
-            N.ops().confidence_accumulate(logits.contiguous(), labels.contiguous(), float(min_unk_score), int(unknown_class),
-                                          int(last_valid), acc)
-    if not losses:
+    losses, counts, rows, chunks = [], [], [], []
+    error = None
+    try:
+        if world > 1:
+            _broadcast_buffers(model, group)
+        from .pipeline import device_batch
+        with torch.no_grad():
+            for batch in data_loader:
+                images, labels = device_batch(batch)
+                logits, features = model(images)
+                j = loss_fn(logits, labels, features) if wants_features else loss_fn(logits, labels)
+                losses.append(j)
+                counts.append(labels.shape[0])
+                if len(rows) % 256 == 0:
+                    chunks.append(torch.zeros(256, 4, dtype=torch.float64, device=logits.device))
+                row = chunks[-1][len(rows) % 256]
+                _confidence_partial(logits, labels, min_unk_score, unknown_class, last_valid, row)
+                rows.append(row)
+    except Exception as e:                 # under data parallel the other ranks wait in the gather below: tell them there
+        if world == 1:
+            raise
+        error = e
+    records = []
+    if losses and error is None:
+        conf = torch.cat(chunks)[:len(rows)].cpu().tolist()
+        records = [(rank + k * world, v, n, c) for k, (v, n, c) in enumerate(zip(torch.stack(losses).cpu().tolist(), counts, conf))]
+    if world > 1:
+        import torch.distributed as dist
+        everyone = [None] * world
+        dist.all_gather_object(everyone, {"records": records, "error": None if error is None else f"{type(error).__name__}: {error}"}, group=group)
+        if error is not None:
+            raise error
+        bad = [(r, e["error"]) for r, e in enumerate(everyone) if e["error"] is not None]
+        if bad:
+            raise RuntimeError(f"validate(): rank {bad[0][0]} failed: {bad[0][1]}")
+        records = sorted(rec for e in everyone for rec in e["records"])
+        if [rec[0] for rec in records] != list(range(len(records))):
+            raise RuntimeError("validate(): the ranks' batches do not tile the batch sequence 0 .. n-1 — the loader is not sharded by "
+                               "whole batches (ShardedEvalBatches(rank, world))")
+    if not records:
         return
-    for value, n in zip(torch.stack(losses).cpu().tolist(), counts):
+    acc = [0.0, 0.0, 0.0, 0.0]
+    for _, value, n, c in records:         # batch order: AverageMeter sees the reference's update sequence, the sums its additions
         trackers["j"].update(value, n)
-    kn_sum, kn_count, neg_sum, neg_count = acc.cpu().tolist()
+        for i in range(4):
+            acc[i] += c[i]
+    kn_sum, kn_count, neg_sum, neg_count = acc
     if kn_count:
         trackers["conf_kn"].update(kn_sum / kn_count, int(kn_count))
     if neg_count:
@@ -210,8 +296,9 @@ def worker(cfg):
     Data parallel (new; the reference only left vestiges, train.py:10,49-50,79-87,248): under `torch.distributed.run` (or the
     CLI launcher driven by the `dist:` block) every rank runs this function on its own GPU (LOCAL_RANK), the training set is
     sharded with a DistributedSampler, the model is wrapped in dp.DistributedDataParallel (bucketed RCCL gradient all-reduce
-    overlapped with backward), `batch_size` is per GPU (train.yaml:18), and only rank 0 validates, logs and writes checkpoints
-    ("Log only on first process. Validate only on first process.", train.py:248).
+    overlapped with backward), `batch_size` is per GPU (train.yaml:18), only rank 0 logs and writes checkpoints ("Log only on first
+    process", train.py:248) — and, departing from "Validate only on first process" (same line), EVERY rank validates its share of the
+    batches (validate(shard=...), `dist.shard_validation`, default on; off = the reference's rule).
 
     `cfg.data.synthetic` (new key, default absent) = number of synthetic training samples to use instead of the CSV files."""
     import logging
@@ -302,7 +389,15 @@ def _worker_body(cfg, log, out_dir, rank, world, distributed):
         lkw.update(persistent_workers=True, prefetch_factor=4 * sub,   # the same number of samples ahead per worker
                    worker_init_fn=worker_init)                         # one intra-op thread per decode worker
     train_loader = torch.utils.data.DataLoader(train_ds, shuffle=sampler is None, sampler=sampler, **lkw)
-    val_loader = torch.utils.data.DataLoader(val_ds, **lkw)
+    # validation (new key dist.shard_validation, default on): under data parallel every rank scores the batches rank, rank + world, ...
+    # of the unshuffled validation sequence (whole batches: validate() replays them in order, bit-identical trackers); off = the
+    # reference's comment "Validate only on first process" (train.py:248)
+    shard_val = distributed and bool(getattr(getattr(cfg, "dist", None), "shard_validation", True))
+    if shard_val:
+        vkw = {k: v for k, v in lkw.items() if k != "batch_size"}
+        val_loader = torch.utils.data.DataLoader(val_ds, batch_sampler=ShardedEvalBatches(len(val_ds), cfg.batch_size, rank, world, sub), **vkw)
+    else:
+        val_loader = torch.utils.data.DataLoader(val_ds, **lkw)
     if prefetch:
         train_loader, val_loader = DevicePrefetcher(train_loader, group=sub), DevicePrefetcher(val_loader, group=sub)
 
@@ -323,9 +418,10 @@ def _worker_body(cfg, log, out_dir, rank, world, distributed):
         log.info(f"Loaded {cfg.checkpoint} at epoch {start_epoch}")
     net = _dp.DistributedDataParallel(model) if distributed else model   # broadcasts rank 0's parameters and BN buffers
     _last_worker_state.clear()
-    _last_worker_state.update(model=model, optimizer=opt, rank=rank, world=world, checkpoints_written=0)
+    _last_worker_state.update(model=model, optimizer=opt, rank=rank, world=world, checkpoints_written=0, sharded_validation=shard_val)
     t_metrics = {"j": _losses.AverageMeter()}
     v_metrics = {"j": _losses.AverageMeter(), "conf_kn": _losses.AverageMeter(), "conf_unk": _losses.AverageMeter()}
+    _last_worker_state.update(v_metrics=v_metrics, val_loader=val_loader, loss_fn=loss_fn, n_classes=n_classes)
     early = _losses.EarlyStopping(patience=cfg.patience) if cfg.patience > 0 else None
     scalars = None
     if rank == 0:
@@ -340,7 +436,11 @@ def _worker_body(cfg, log, out_dir, rank, world, distributed):
         train(net, train_loader, opt, loss_fn, t_metrics, cfg)
         t1 = time.time()
         stop, failure = False, None
-        if rank == 0:                                     # validate / log / checkpoint on the first process only
+        curr_score = None
+        if shard_val:                                     # every rank scores its share of the batches; all ranks end with the same trackers
+            validate(model, val_loader, loss_fn, n_classes, v_metrics, cfg, shard=(rank, world))
+            curr_score = v_metrics["conf_kn"].avg + v_metrics["conf_unk"].avg
+        elif rank == 0:                                   # validate on the first process only (reference train.py:248)
             try:
                 validate(model, val_loader, loss_fn, n_classes, v_metrics, cfg)
                 curr_score = v_metrics["conf_kn"].avg + v_metrics["conf_unk"].avg

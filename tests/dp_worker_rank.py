@@ -22,10 +22,21 @@ def main():
     st = T._last_worker_state
     import torch
     torch.cuda.synchronize()
+    # validation on every rank (train.validate(shard=...)): this rank's trackers after the last epoch, and — same model, same process —
+    # the single-process loop over the WHOLE validation set (the reference's "validate only on first process" computation)
+    meters = lambda tr: {k: [m.val, m.avg, m.sum, m.count] for k, m in tr.items()}
+    sharded = meters(st["v_metrics"])
+    from openset_imagenet import losses as L
+    ds = st["val_loader"].loader.dataset if hasattr(st["val_loader"], "loader") else st["val_loader"].dataset
+    whole = torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size)
+    single = {"j": L.AverageMeter(), "conf_kn": L.AverageMeter(), "conf_unk": L.AverageMeter()}
+    T.validate(st["model"], whole, st["loss_fn"], st["n_classes"], single, cfg)
     h = hashlib.sha1(st["model"].flat_parameters().cpu().numpy().tobytes()).hexdigest()
     hb = hashlib.sha1(st["model"]._flat_buffers.cpu().numpy().tobytes()).hexdigest()
     print("RESULT " + json.dumps({"rank": st["rank"], "world": st["world"], "params": h, "buffers": hb,
-                                  "checkpoints_written": st["checkpoints_written"], "best": best}), flush=True)
+                                  "checkpoints_written": st["checkpoints_written"], "best": best,
+                                  "sharded_validation": st["sharded_validation"], "v_sharded": sharded, "v_single": meters(single),
+                                  "val_samples": len(ds)}), flush=True)
 
 
 if __name__ == "__main__":

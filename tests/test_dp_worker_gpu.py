@@ -2,7 +2,8 @@
 epoch. RCCL cannot place two ranks on the one GPU of the test box, so `dist.backend: gloo` carries the collectives here (GPU
 tensors over gloo); everything else is the production path: RANK / WORLD_SIZE / LOCAL_RANK from the launcher, process group
 initialised inside worker(), DistributedSampler shards, dp.DistributedDataParallel wrap (broadcast + bucketed all-reduce per
-backward stage), rank-0-only validation / logging / checkpoints (reference intent: train.py:248, train.yaml:18,35-39)."""
+backward stage), validation on every rank (whole batches, trackers bit-identical to the single-process loop), rank-0-only logging /
+checkpoints (reference intent: train.py:248, train.yaml:18,35-39)."""
 import json
 import os
 import socket
@@ -55,6 +56,13 @@ def test_worker_two_ranks_one_epoch(cuda, tmp_path):
     assert res[0]["params"] == res[1]["params"], "replicas diverged: parameters differ between the ranks after the epoch"
     assert res[0]["checkpoints_written"] >= 1 and res[1]["checkpoints_written"] == 0, "only the first process writes checkpoints"
     assert res[0]["best"] == res[1]["best"]
+    # validation ran on BOTH ranks (each scored the batches rank, rank + 2, ... of the unshuffled validation set: 6 samples at batch 4 =
+    # one whole batch + a ragged one) and both hold the trackers a single process computes on the whole set, bit for bit
+    for r in res:
+        assert r["sharded_validation"] is True and r["val_samples"] == 6
+        assert r["v_sharded"] == r["v_single"], f"rank {r['rank']}: sharded {r['v_sharded']} vs single-process {r['v_single']}"
+        assert r["v_sharded"]["j"][3] == 6
+    assert res[0]["v_sharded"] == res[1]["v_sharded"]
     files = sorted(f.name for f in out.iterdir())
     assert "experiment_curr.pth" in files and "training.log" in files and "scalars-training.log.csv" in files
     ck = torch.load(out / "experiment_curr.pth", weights_only=False)

@@ -1,0 +1,173 @@
+"""Validation on every rank (CPU, gloo, world 2 and 4): validate(shard=(rank, world)) of this package against its own single-process
+validate() on the whole loader — the trackers (val, avg, sum, count of j, conf_kn, conf_unk) must be BIT-identical, ragged last batch
+included. The reference validates on the first process only (comment at /root/reference/openset_imagenet/train.py:248; loop
+train.py:142-196, metrics.py:8-42); sharding by WHOLE batches keeps every per-batch loss the value the single-process loop computes,
+and the replay in batch order keeps AverageMeter's update sequence and the order of the confidence additions.
+
+The per-batch confidence kernel is HIP-only (the product has no CPU path); here it is replaced by the oracle's restatement of
+metrics.confidence — the sharding / gather / replay logic under test is the product's."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_sharded_eval_batches_tile_the_reference_batch_sequence():
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    sys.path[:0] = [os.path.join(root, "openset-imagenet_amd")]
+    from openset_imagenet.train import ShardedEvalBatches
+    for n, B, world, sub in ((103, 8, 4, 1), (103, 8, 4, 4), (64, 16, 2, 2), (5, 8, 4, 2), (0, 8, 2, 1), (129, 128, 8, 4)):
+        ref = [list(range(k, min(n, k + B))) for k in range(0, n, B)]            # DataLoader(ds, batch_size=B): unshuffled, ragged tail kept
+        got = {}
+        for r in range(world):
+            s = ShardedEvalBatches(n, B, r, world, sub)
+            subs = list(s)
+            assert len(subs) == len(s)
+            assert all(0 < len(x) <= B // sub for x in subs)
+            # regroup `sub` consecutive sub-batches as DevicePrefetcher(group=sub) does
+            ks = list(s.batches())
+            i = 0
+            for k in ks:
+                want = ref[k]
+                take = -(-len(want) // (B // sub))
+                got[k] = [v for x in subs[i:i + take] for v in x]
+                i += take
+            assert i == len(subs)
+            assert ks == list(range(r, len(ref), world))
+        assert [got[k] for k in sorted(got)] == ref
+    with pytest.raises(ValueError):
+        ShardedEvalBatches(10, 8, 2, 2)
+    with pytest.raises(ValueError):
+        ShardedEvalBatches(10, 8, 0, 1, sub=3)
+
+
+class _Tiny(torch.nn.Module):
+    def __init__(self, C):
+        super().__init__()
+        self.body = torch.nn.Linear(3 * 4 * 4, 12, bias=False)
+        self.bn = torch.nn.BatchNorm1d(12)
+        self.logits = torch.nn.Linear(12, C)
+
+    def forward(self, x):
+        f = torch.relu(self.bn(self.body(x.flatten(1))))
+        return self.logits(f), f
+
+
+def _meters(tr):
+    return {k: (m.val, m.avg, m.sum, m.count) for k, m in tr.items()}
+
+
+def _worker(rank, world, port, out, mode):
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    sys.path[:0] = [root, os.path.join(root, "openset-imagenet_amd")]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openset_imagenet import losses as L, tools, train as T
+        from openset_imagenet.util import NameSpace
+        from oracle import losses_oracle as LO
+        tools.set_device_cpu()
+
+        def conf_partial(logits, labels, offset, unknown_class, last_valid, row):      # metrics.confidence's sums for ONE batch (oracle)
+            scores = torch.softmax(logits, dim=1)
+            kc, kn, nc, nn = LO.confidence(scores, labels, offset, unknown_class, None if last_valid == 0 else last_valid)
+            row += torch.tensor([kc * kn, kn, nc * nn, nn], dtype=torch.float64)
+        T._confidence_partial = conf_partial
+
+        C, B = 5, 8
+        for loss_type in ("entropic", "garbage"):
+            torch.manual_seed(0)
+            model = _Tiny(C)
+            with torch.no_grad():                     # running statistics that DIFFER per rank: validate() must score rank 0's model everywhere
+                model.bn.running_mean.copy_(torch.randn(12, generator=torch.Generator().manual_seed(50 + rank)) * 0.3)
+                model.bn.running_var.copy_(torch.rand(12, generator=torch.Generator().manual_seed(60 + rank)) + 0.5)
+            g = torch.Generator().manual_seed(3)
+            sizes = [B] * 6 + [3]                     # 7 batches, ragged tail: world 2 -> 4 + 3, world 4 -> 2 + 2 + 2 + 1
+            batches = []
+            for n in sizes:
+                y = torch.randint(0, C, (n,), generator=g)
+                if loss_type == "entropic":
+                    y[torch.rand(n, generator=g) < 0.4] = -1
+                batches.append((torch.rand(n, 3, 4, 4, generator=g), y))
+            if loss_type == "entropic":
+                loss_fn = lambda z, y: LO.entropic_openset_loss(z, y, 1.0)
+            else:
+                w = torch.rand(C, generator=g) + 0.5
+                loss_fn = lambda z, y: LO.garbage_loss(z, y, w)
+            cfg = NameSpace({"parallel": True, "batch_size": B, "loss": {"type": loss_type}})
+            mk = lambda: {"j": L.AverageMeter(), "conf_kn": L.AverageMeter(), "conf_unk": L.AverageMeter()}
+            if mode == "parity":
+                sharded = mk()
+                T.validate(model, batches[rank::world], loss_fn, C, sharded, cfg, shard=(rank, world))
+                assert not model.training
+                # rank 0's buffers are now everywhere
+                rm = [torch.zeros(12) for _ in range(world)]
+                dist.all_gather(rm, model.bn.running_mean.clone())
+                assert all(torch.equal(a, rm[0]) for a in rm)
+                single = mk()
+                T.validate(model, batches, loss_fn, C, single, cfg)       # the whole loader in one process: the reference's loop
+                assert _meters(sharded) == _meters(single), (loss_type, _meters(sharded), _meters(single))
+                assert single["j"].count == sum(sizes) and single["conf_kn"].count + single["conf_unk"].count <= sum(sizes)
+                out.put((rank, loss_type, _meters(sharded)))
+            elif mode == "fail":                      # one rank fails in its loop: EVERY rank raises, nobody is left in a collective
+                def boom(z, y):
+                    raise ValueError("bad batch")
+                try:
+                    T.validate(model, batches[rank::world], boom if rank == world - 1 else loss_fn, C, mk(), cfg, shard=(rank, world))
+                    out.put((rank, loss_type, "no error"))
+                except ValueError as e:
+                    out.put((rank, loss_type, f"own:{e}"))
+                except RuntimeError as e:
+                    out.put((rank, loss_type, f"remote:{e}"))
+            else:                                     # rank 0 feeds the WHOLE loader, the others their share: the streams do not interleave to 0 .. n-1
+                try:
+                    T.validate(model, batches if rank == 0 else batches[rank::world], loss_fn, C, mk(), cfg, shard=(rank, world))
+                    out.put((rank, loss_type, "no error"))
+                except RuntimeError as e:
+                    out.put((rank, loss_type, f"remote:{e}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, mode):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return sorted(out.get(timeout=5) for _ in range(2 * world))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_validation_is_bit_identical_to_the_single_process_loop(world):
+    res = _run(world, "parity")
+    for loss_type in ("entropic", "garbage"):
+        per_rank = [m for _, lt, m in res if lt == loss_type]
+        assert len(per_rank) == world and all(m == per_rank[0] for m in per_rank), "every rank ends with the same trackers"
+
+
+@pytest.mark.timeout(600)
+def test_a_failing_rank_fails_every_rank():
+    res = _run(2, "fail")
+    for rank, _, msg in res:
+        assert msg == ("own:bad batch" if rank == 1 else "remote:validate(): rank 1 failed: ValueError: bad batch"), res
+
+
+@pytest.mark.timeout(600)
+def test_streams_that_do_not_interleave_are_refused():
+    res = _run(2, "tiling")
+    assert all(msg.startswith("remote:validate(): the ranks' batches do not tile") for _, _, msg in res), res
