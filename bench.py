@@ -466,11 +466,15 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=None,
                     help="further steps AFTER the timed windows (never part of `value`), reported as `sustained` in 50-step windows; 0 = off. "
                          "Default 600 (OSI_BENCH_SUSTAINED), and 0 for dev runs (--no-profile or --windows 1: A/B and counter passes)")
+    ap.add_argument("--eval-steps", type=int, default=None, help="inference leg after everything else (never part of `value`): eval-mode forwards "
+                    "timed per mode; 0 = off. Default 20, and 0 for dev runs (--no-profile or --windows 1)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 self-launch: seconds before the ranks are terminated")
     ap.add_argument("--bind", default="auto", choices=("auto", "near", "even", "none"), help="N > 1 self-launch: CPU binding of the ranks")
     args = ap.parse_args()
     if args.sustained_steps is None:
         args.sustained_steps = 0 if (args.no_profile or args.windows == 1) else int(os.environ.get("OSI_BENCH_SUSTAINED", "600"))
+    if args.eval_steps is None:
+        args.eval_steps = 0 if (args.no_profile or args.windows == 1) else 20
     if args.windows < 1 or args.steps < 1 or args.warmup < 0 or args.cpus_per_gpu < 1 or args.sustained_steps < 0:
         ap.error("--windows, --steps and --cpus-per-gpu must be >= 1, --warmup and --sustained-steps >= 0")
 
@@ -692,6 +696,58 @@ def main():
         names = ["start", "conv_fwd", "conv_dgrad", "conv_wgrad", "bn_fwd", "bn_bwd", "other"]
         prof = {n: {"ms_per_step": ms[i] / psteps, "launch_groups_per_step": cnt[i] / psteps} for i, n in enumerate(names) if i}
 
+    # Inference leg (never part of `value`): the forward of validate() / get_arrays() (reference train.py:142-234: model.eval(), no_grad)
+    # on the same resident batch — the training topology on running statistics (executor option eval_fused = 0: pre-BN tensors, 16
+    # block-output passes, bitmasks, 53 coefficient launches) against the inference forms (default: every BatchNorm + shortcut + ReLU in
+    # its convolution's epilogue), and one validation step (forward + loss + confidence sums) as validate() issues it.
+    evalrec = None
+    if args.eval_steps > 0:
+        def timed_forward(n, extra=None):
+            with torch.no_grad():
+                for _ in range(3):
+                    lg, ft = model(images)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    lg, ft = model(images)
+                    if extra is not None:
+                        extra(lg)
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        def class_ms():
+            N.check(N.lib().osi_resnet50_profile(handle, 1))
+            with torch.no_grad():
+                for _ in range(3):
+                    model(images)
+            torch.cuda.synchronize()
+            ms, cnt = (ctypes.c_double * 7)(), (ctypes.c_int * 7)()
+            N.check(N.lib().osi_resnet50_profile_read(handle, ms, cnt))
+            N.check(N.lib().osi_resnet50_profile(handle, 0))
+            return {"conv_ms": round(ms[1] / 3, 3), "bn_ms": round(ms[4] / 3, 3), "other_ms": round(ms[6] / 3, 3),
+                    "launch_groups": int(sum(cnt[1:]) / 3)}
+        model.eval()
+        evalrec = {}
+        for name, fused in (("training_topology", 0), ("fused", 1)):
+            N.check(N.lib().osi_resnet50_set_option(handle, b"eval_fused", fused))
+            t = timed_forward(args.eval_steps)
+            evalrec[name] = {"ms_per_batch": round(t * 1e3, 3), "images_per_sec": round(B / t, 1)}
+            if not args.no_profile:
+                evalrec[name]["serialized"] = class_ms()
+        acc4 = torch.zeros(4, dtype=torch.float64, device=dev)
+        def val_tail(lg):
+            loss_fn(lg, labels)
+            if wl["loss"] == "garbage":
+                N.ops().confidence_accumulate(lg, labels, 0.0, C - 1, -1, acc4)
+            else:
+                N.ops().confidence_accumulate(lg, labels, 1.0 / C, -1, 0, acc4)
+        t = timed_forward(args.eval_steps, val_tail)
+        evalrec["validate_step"] = {"ms_per_batch": round(t * 1e3, 3), "images_per_sec": round(B / t, 1),
+                                    "what": "fused forward + loss + confidence sums per batch, as train.validate() issues them (no host sync inside)"}
+        evalrec.update(batch=B, steps=args.eval_steps, speedup=round(evalrec["training_topology"]["ms_per_batch"] / evalrec["fused"]["ms_per_batch"], 3),
+                       how=f"{args.eval_steps} eval-mode forwards of the resident batch after 3 warm-ups, one synchronize around the loop; per rank "
+                           "(validation is sharded over the ranks by whole batches: the node's rate is world x this)")
+        model.train()
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         ips = world * B * args.steps / elapsed
@@ -734,6 +790,8 @@ def main():
                                   "tflops": round(B * g / v["ms_per_step"], 2) if g else None}
                               for (k, v), g in zip(prof.items(), (CONV_GFLOP_FWD, CONV_GFLOP_DGRAD, CONV_GFLOP_WGRAD, 0, 0, 0))},
             }
+        if evalrec is not None:
+            out["eval"] = evalrec
         if sustained is not None:
             sustained["vs_value"] = round(sustained["images_per_sec"] / out["value"], 4)
             out["sustained"] = sustained
