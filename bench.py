@@ -365,6 +365,51 @@ def committed_traffic(ms_step, B, workload):
     return round(total * 1e9), prov
 
 
+def committed_mfma_util(ms_step, B, workload):
+    """Matrix-pipe busy share per conv class (and the measured issued FLOPs) from the newest committed counter summary
+    (profiles/rNN_mfma_util.json), under the provenance rule of committed_traffic: a profile of another workload, or one whose step time
+    is more than 15 % off this run, is named but not reported."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json")))
+    if not files:
+        return None, None, {"file": None}
+    path = files[-1]
+    t = json.load(open(path))
+    meta = t.get("_meta") or {}
+    prov = {"file": os.path.relpath(path, ROOT), "git_blob": _git_blob_id(path), "profiled_ms_per_step": meta.get("ms_per_step"),
+            "profiled_workload": meta.get("workload"), "profiled_commit": meta.get("commit")}
+    fresh = meta.get("workload") == workload and meta.get("batch") == B and meta.get("ms_per_step") \
+        and abs(meta["ms_per_step"] - ms_step) <= 0.15 * ms_step
+    prov["matches_this_run"] = bool(fresh)
+    if not fresh:
+        return None, None, prov
+    busy = {k: t["mfma_busy_percent"].get(k) for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
+    return busy, t.get("issued_gflop_per_step_measured"), prov
+
+
+# the thirteen 3x3 / stride 1 / pad 1 layers of ResNet-50 (conv2 of every bottleneck without a stride; SURVEY.md Appendix A): (channels, H, count)
+WINO_LAYERS = ((64, 56, 3), (128, 28, 3), (256, 14, 5), (512, 7, 2))
+
+
+def issued_conv_gflop(B, lib):
+    """Matrix FLOPs the conv kernels ISSUE per step, per class. The direct kernels issue the convolution's own multiplies (SURVEY.md section 8d:
+    what `roofline.achieved` counts); a Winograd layer issues 16 transform-domain products per 2x2 output tile and channel pair instead of
+    36 — 4/9, times the tile padding where the image is not a whole number of tiles (7 x 7: 16 tiles cover 64 pixel slots for 49 pixels).
+    Which directions run Winograd is read from the library's knobs."""
+    knob = ctypes.c_int()
+    out = {}
+    for cls, gf, name in (("conv_fwd", CONV_GFLOP_FWD, b"fwd_wino"), ("conv_dgrad", CONV_GFLOP_DGRAD, b"dgrad_wino"), ("conv_wgrad", CONV_GFLOP_WGRAD, b"wgrad_wino")):
+        total = gf * B
+        lib.osi_get_tuning(name, ctypes.byref(knob))
+        if knob.value:
+            for C, H, count in WINO_LAYERS:
+                direct = 2.0 * H * H * C * C * 9 * count * B / 1e9
+                tiles = ((H + 1) // 2) ** 2
+                total += 2.0 * tiles * 16 * C * C * count * B / 1e9 - direct
+        out[cls] = total
+    return out
+
+
 def parity_probe(model, C, device):
     """Same-run logits parity on one shared batch with shared (freshly initialised) weights: HIP path vs the CPU oracle in fp32
     and in fp64 (the arbiter: torch-CPU fp32 is itself a few 1e-5 away from fp64 on this network)."""
@@ -770,9 +815,25 @@ def main():
             # measurement of this same command committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE, KiB units, the x2 is the
             # gfx950 wide-read correction of MI355X_MICROARCH.md, validated on the Adam kernel's known 380/285 MB).
             traffic, tprov = committed_traffic(ms_step, B, args.workload)
+            issued = issued_conv_gflop(B, N.lib())
+            issued_total = sum(issued.values())
+            busy, issued_measured, mprov = committed_mfma_util(ms_step, B, args.workload)
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                "frac_is": "EFFECTIVE rate: the direct convolution's FLOPs (SURVEY.md section 8d) over the conv kernels' time over the peak — the Winograd "
+                           "layers' 2.25x fewer multiplies show as rate, so a single kernel can exceed 1; `issued_frac` is the matrix pipe's own utilisation",
+                "issued_gflop_per_step": round(issued_total, 1),
+                "issued_frac": round(issued_total * 1e9 / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                "issued_per_class_gflop": {k: round(v, 1) for k, v in issued.items()},
+                "issued_how": "matrix FLOPs the kernels issue: direct layers = the convolution's multiplies, Winograd layers (knobs fwd_wino / dgrad_wino / "
+                              "wgrad_wino) = 16 products per 2x2 tile and channel pair incl. border-tile padding; over the same event-timed conv time",
+                "mfma_busy_percent": busy, "issued_gflop_per_step_measured": issued_measured,
+                "mfma_busy_provenance": mprov,
+                "mfma_busy_note": "share of each class's launches during which a SIMD's matrix pipe is busy (rocprofv3 --pmc MfmaUtil) and the issued "
+                                  "FLOPs measured as SQ_VALU_MFMA_BUSY_CYCLES x 64, from the committed summary named in mfma_busy_provenance; null when that "
+                                  "profile is of another workload or its step time is >15% off this run",
+                "traffic": traffic,
                 "traffic_provenance": tprov,
                 "traffic_note": "bytes per step at the L2<->fabric boundary for the three conv kernel classes, from the committed "
                                 "rocprofv3 PMC summary named in traffic_provenance (--pmc FETCH_SIZE / WRITE_SIZE, separate passes); null "

@@ -112,11 +112,34 @@ def main():
     mf = os.path.join(src, "MfmaUtil", "p_counter_collection.csv")
     if os.path.isfile(mf):
         util = mfma_util_per_class(mf)
+        rec = {"_note": "rocprofv3 --pmc MfmaUtil over `bench.py --steps 3 --warmup 1` (kernels serialised by the counter "
+                        "collection): duration-weighted mean per kernel class of 100 * SQ_VALU_MFMA_BUSY_CYCLES / "
+                        "(GRBM_GUI_ACTIVE * SIMDs) — share of the launch during which the matrix pipe of a SIMD is busy",
+               "_meta": out.get("_meta"), "mfma_busy_percent": util}
+        # matrix FLOPs actually ISSUED per step: every cycle a SIMD's matrix pipe is busy retires 64 FLOP (v_mfma_f32_32x32x2_f32: 4096 FLOP
+        # in 64 cycles; 16x16x4: 2048 in 32), so busy cycles x 64 counts the multiplies the kernels really executed — the Winograd layers'
+        # 4/9, border tiles and ragged-tile padding included
+        mi = os.path.join(src, "MfmaIssued", "p_counter_collection.csv")
+        if os.path.isfile(mi):
+            busy, insts, steps = defaultdict(float), defaultdict(float), 0
+            seen = set()
+            with open(mi) as fh:
+                for row in csv.DictReader(fh):
+                    k = klass(row["Kernel_Name"])
+                    if row["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                        busy[k] += float(row["Counter_Value"])
+                    elif row["Counter_Name"] == "SQ_INSTS_MFMA":
+                        insts[k] += float(row["Counter_Value"])
+                    if "k_adam" in row["Kernel_Name"] and row["Dispatch_Id"] not in seen:
+                        seen.add(row["Dispatch_Id"]); steps += 1
+            if steps:
+                rec["issued_gflop_per_step_measured"] = {k: round(busy[k] * 64 / steps / 1e9, 1) for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
+                rec["issued_gflop_per_step_measured"]["total"] = round(sum(rec["issued_gflop_per_step_measured"].values()), 1)
+                rec["mfma_instructions_per_step"] = {k: round(insts[k] / steps) for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
+                rec["_note"] += ("; issued_gflop_per_step_measured = SQ_VALU_MFMA_BUSY_CYCLES x 64 FLOP per busy SIMD cycle, per step "
+                                 f"({steps} steps seen): the matrix work really executed (Winograd 4/9, border tiles, tile padding included)")
         with open(os.path.join(dst, f"{tag}_mfma_util.json"), "w") as f:
-            json.dump({"_note": "rocprofv3 --pmc MfmaUtil over `bench.py --steps 3 --warmup 1` (kernels serialised by the counter "
-                                "collection): duration-weighted mean per kernel class of 100 * SQ_VALU_MFMA_BUSY_CYCLES / "
-                                "(GRBM_GUI_ACTIVE * SIMDs) — share of the launch during which the matrix pipe of a SIMD is busy",
-                       "mfma_busy_percent": util}, f, indent=1)
+            json.dump(rec, f, indent=1)
         print("MfmaUtil", util)
     with open(os.path.join(dst, f"{tag}_hbm_traffic_per_step.json"), "w") as f:
         json.dump(out, f, indent=1)
