@@ -12,7 +12,7 @@ for r in $(seq $R); do
   for v in "${LIBS[@]}"; do
     cp $v $L
     echo -n "$(basename $v)  "
-    python bench.py --steps 20 --warmup 10 --no-cpu-baseline --sustained-steps 0 "$@" 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['frac'])" || { cp /tmp/libosi_hip_keep.so $L; exit 1; }
+    python bench.py --steps 20 --warmup 10 --no-cpu-baseline --sustained-steps 0 --eval-steps 0 "$@" 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['frac'])" || { cp /tmp/libosi_hip_keep.so $L; exit 1; }
   done
 done
 cp /tmp/libosi_hip_keep.so $L
