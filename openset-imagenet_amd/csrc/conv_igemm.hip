@@ -149,10 +149,6 @@ __device__ __forceinline__ bool tile_of_block_split(const ConvP& p, int bid, int
 #ifndef OSI_ABLATE
 #define OSI_ABLATE 0
 #endif
-// epilogue of the "block input" input gradient (dgrad_epilogue64<3>): 1 = phased (four rows' loads in flight together), 0 = one row at a time
-#ifndef OSI_DG3_PHASES
-#define OSI_DG3_PHASES 1
-#endif
 
 // ---- MFMA over one LDS stage -------------------------------------------------------------------------
 // A: R image (rows = GEMM rows), B: R image (rows = GEMM cols)
@@ -630,11 +626,9 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
 // FUSED: 0 = addend only; 1 = every fusion the ABI allows (tests, pool mode); 2 = "in-block" (the gate recomputed from y0 and / or
 // the sums over y0; no addend, bitmask or second consumer: all four rows' loads in flight); 3 = "block input" (addend, bitmask,
 // sums over y0 and y1; no recomputed gate). 2 and 3 are what the executor issues; they exist so that each fits 64 registers.
-// `keep(row, c4, v)` / `kept(row, c4)`: parking place of the gated gradient between the two phases of the "block input" form (FUSED = 3) —
-// the LDS tile in the convolution kernel, registers in the fix-up pass.
-template <int FUSED, bool POOL, typename RD, typename KEEP, typename KEPT>
+template <int FUSED, bool POOL, typename RD>
 __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, int cls, int mt, int m0, int n0, int Mc, int st, int ph,
-                                                 int pw, const FastDiv& dHW, const FastDiv& dW, RD rd, KEEP keep, KEPT kept) {
+                                                 int pw, const FastDiv& dHW, const FastDiv& dW, RD rd) {
     constexpr int BN = 64;
     constexpr bool USE_ADD = FUSED != 2, USE_BITS = FUSED == 1 || FUSED == 3, USE_Y1 = FUSED == 1 || FUSED == 3;
     constexpr bool USE_GATE = FUSED == 1 || FUSED == 2;
@@ -651,10 +645,9 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
     const bool has_y1 = USE_Y1 && has_sum && p.ey1 != nullptr;
     const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.y, FULL);
     f32x4 sg = {0, 0, 0, 0}, s0 = sg, s1 = sg, mu0 = sg, is0 = sg, gsc = sg, gsh = sg;
-    constexpr bool PHASED3 = FUSED == 3 && OSI_DG3_PHASES;      // (loads its per-channel vectors in front of its second phase)
     if (FUSED) {
         const uint32_t cb = (uint32_t)col * 4u;
-        if (!PHASED3) { mu0 = bld4(make_rsrc(p.emean0, has_sum ? FULL : 0), cb, 0); is0 = bld4(make_rsrc(p.einv0, has_sum ? FULL : 0), cb, 0); }
+        mu0 = bld4(make_rsrc(p.emean0, has_sum ? FULL : 0), cb, 0); is0 = bld4(make_rsrc(p.einv0, has_sum ? FULL : 0), cb, 0);
         if (USE_GATE) { gsc = bld4(make_rsrc(p.escale0, has_gate ? FULL : 0), cb, 0); gsh = bld4(make_rsrc(p.eshift0, has_gate ? FULL : 0), cb, 0); }
     }
     uint32_t pixv[POOL ? 4 : 1], offb[4];    // pixel index and BYTE offset of this lane's float4 in row k; OOB past the tensor
@@ -689,69 +682,6 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
             sg += v;
             s0 += (v * (y0v[k] - mu0)) * is0;
             bst4(r_out, v, offb[k], 0);
-        }
-    } else if constexpr (FUSED == 3 && OSI_DG3_PHASES) {
-        // "block input", phased: the per-row form below keeps ONE row's loads in flight (four dependent memory round trips per tile — what a
-        // short-K launch, K = 128 / 256 at 28 x 28 / 14 x 14, spends most of its life in). Phase A: addend + mask words of all FOUR rows go
-        // out together; the gated gradient is stored and parked (`keep`: back into the LDS tile it came from, each lane its own slots).
-        // Phase B: y0 / y1 of two rows at a time for the sums. Three round trips of four / two / two rows instead of four of one, within
-        // the 64 registers of eight waves per SIMD. Same values, same order of every sum: bit-identical to the per-row form.
-        const __amdgpu_buffer_rsrc_t r_add = make_rsrc(p.addend, p.addend ? FULL : 0);
-        const __amdgpu_buffer_rsrc_t r_bits = make_rsrc(reinterpret_cast<const float*>(p.ebits), has_bits ? FULL : 0);
-        const __amdgpu_buffer_rsrc_t r_y1 = make_rsrc(p.ey1, has_y1 ? FULL : 0);
-        {
-            f32x4 av[4];
-            uint32_t wb[4][4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int rl = rg + 16 * k;
-                const uint32_t apix = (uint32_t)(m0 + rl), ab = fdiv(apix, dHW), arem = apix - ab * dHW.d, ah = fdiv(arem, dW), aw = arem - ah * dW.d;
-                const uint32_t aoff = (((ah | aw) & (uint32_t)p.eadd_even) != 0u) ? OOB : offb[k];
-                av[k] = bld4(r_add, aoff, 0);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t i4 = offb[k] >> 4, bit = i4 & 63u;
-                const uint32_t boff = offb[k] != OOB ? (i4 >> 6) * 32u + (bit >> 5) * 4u : OOB;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wb[k][e] = __builtin_amdgcn_raw_buffer_load_b32(r_bits, boff, 8 * e, 0);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                f32x4 v = rd(rg + 16 * k, c4);
-                v += av[k];
-                const uint32_t bit = (offb[k] >> 4) & 31u;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool on = (((wb[k][e] >> bit) & 1u) != 0) | !has_bits;
-                    v[e] = on ? v[e] : 0.f;
-                }
-                keep(rg + 16 * k, c4, v);
-                bst4(r_out, v, offb[k], 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);          // phase B's loads stay behind phase A's arithmetic (its registers are free by then)
-        {
-            const uint32_t cb = (uint32_t)col * 4u;
-            mu0 = bld4(make_rsrc(p.emean0, has_sum ? FULL : 0), cb, 0); is0 = bld4(make_rsrc(p.einv0, has_sum ? FULL : 0), cb, 0);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f32x4 y0v[2], y1v[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { y0v[j] = bld4(r_y0, offb[2 * h + j], 0); y1v[j] = bld4(r_y1, offb[2 * h + j], 0); }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x4 v = kept(rg + 16 * (2 * h + j), c4);
-                sg += v;
-                s0 += (v * (y0v[j] - mu0)) * is0;
-                s1 += v * y1v[j];
-            }
-        }
-        {
-            const uint32_t cb = (uint32_t)col * 4u;
-            const f32x4 mu1 = bld4(make_rsrc(p.emean1, has_y1 ? FULL : 0), cb, 0), is1 = bld4(make_rsrc(p.einv1, has_y1 ? FULL : 0), cb, 0);
-            s1 = (s1 - mu1 * sg) * is1;
         }
     } else {
         const __amdgpu_buffer_rsrc_t r_add = make_rsrc(p.addend, (USE_ADD && p.addend) ? FULL : 0);
@@ -1092,8 +1022,6 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN >= 4 ? 3 : (WM * WN == 1 ?
             return;
         }
         dgrad_epilogue64<FUSED, POOL>(p, smem, cls, mt, m0, n0, Mc, st, ph, pw, dHW, dW,
-                                [&](int rl, int c4) { return *reinterpret_cast<const f32x4*>(tile + rl * LDT + c4 * 4); },
-                                [&](int rl, int c4, const f32x4& v) { *reinterpret_cast<f32x4*>(tile + rl * LDT + c4 * 4) = v; },
                                 [&](int rl, int c4) { return *reinterpret_cast<const f32x4*>(tile + rl * LDT + c4 * 4); });
         OSI_STAMP(p, sidx, 3);
         return;
@@ -1912,7 +1840,6 @@ __global__ __launch_bounds__(256) void k_conv_dgrad_tail_fixup(ConvP p) {
     const int nsp = p.ks_S;
     // one descriptor over the tile's slabs: splits past nsp read as zero, so eight loads go out together; sums stay in split order
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.ks_slab + (size_t)tile * nsp * 4096, nsp * 16384);
-    f32x4 parked[4];      // rows rg + 16 k of this lane (k = row >> 4)
     dgrad_epilogue64<FUSED, false>(p, red, 0, mt, mt * 64, nt * 64, p.B * p.H * p.W, 1, 0, 0, p.cHW[0], p.cW[0], [&](int rl, int c4) {
         const uint32_t off = (uint32_t)(rl * 64 + c4 * 4) * 4u;
         f32x4 a = bld4(rs, off, 0);
@@ -1924,7 +1851,7 @@ __global__ __launch_bounds__(256) void k_conv_dgrad_tail_fixup(ConvP p) {
             for (int j = 0; j < 8; ++j) a += t[j];
         }
         return a;
-    }, [&](int rl, int, const f32x4& v) { parked[rl >> 4] = v; }, [&](int rl, int) { return parked[rl >> 4]; });
+    });
 }
 
 // out[i] = sum_s slab[s][i]  (fixed order: bitwise reproducible)

@@ -56,5 +56,5 @@ for Cin, Cout, H, cons, sparse, count in SHAPES:
     byt = 4.0 * M * (Cout + Cin * (1 + cons + (0.25 if sparse else 1.0)) + Cin / 32.0)
     t_mfma, t_hbm = gf / 157.3e3 * 1e3, byt / 6.0e12 * 1e3
     total += ms * count
-    print(f"  {Cin:4d}->{Cout:3d} @{H:2d} c{cons}{' sparse' if sparse else '       '} {ms * 1e3:8.1f}  {gf / ms / 1e3:8.1f}   {t_mfma / ms:8.2f}      {t_hbm / ms:8.2f}              x{count}", flush=True)
+    print(f"  {Cin:4d}->{Cout:3d} @{H:2d} c{cons}{' sparse' if sparse else '       '} {ms * 1e3:8.1f}  {gf / ms:8.1f}   {t_mfma / ms:8.2f}      {t_hbm / ms:8.2f}              x{count}", flush=True)
 print(f"sum over the step's 15 launches: {total:.3f} ms")
