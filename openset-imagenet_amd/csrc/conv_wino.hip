@@ -31,6 +31,7 @@
 //     tensor (fma(y0, scale0, shift0) > 0), and the per-64-pixel sums of g and g * xhat0 for the BatchNorm backward of that producer.
 #include "conv_common.h"
 #include <algorithm>
+#include <type_traits>
 #include <utility>
 
 using namespace osi_conv;
@@ -83,6 +84,29 @@ struct WinoP {
     float* slab;
     int slab_bytes;
 };
+
+// Two fp32 adds / subtracts per lane in one instruction. Written as asm: left to itself the compiler scalarises <2 x float> arithmetic
+// inside the pinned slice loop (v_add_f32_e64 per element), and the statement order is part of the kernel's schedule anyway.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_add(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_add(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_sub(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_sub(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
 
 template <class F, int... I>
 __device__ __forceinline__ void for_each_const(F& f, std::integer_sequence<int, I...>) {
@@ -363,12 +387,14 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
     const uint32_t ustep = (uint32_t)p.CB * 2048;      // bytes per (position, slice) block of U
 
     f32x16 acc[16];
-    f32x4 xr[16];                    // WIDE: elements 0, 1 only
+    // the thread's 4 x 4 patch, NV channels per pixel. The transforms below are written on whole XT vectors: fp32 MFMAs hide no vector work
+    // (profiles/r06_mfma_valu_coexec.txt), so every instruction counts, and two adds in one v_pk_add_f32 cost a lone wave 5.6 cycles
+    // against 2 x 4.7 for the scalar pair
+    using XT = std::conditional_t<WIDE, f32x2, f32x4>;
+    XT xr[16];
     auto load_x1 = [&](int ks, int k) {
-        if constexpr (WIDE) {
-            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, off[k], (uint32_t)ks * (KC * 4), 0));
-            xr[k][0] = v[0]; xr[k][1] = v[1];
-        } else xr[k] = bld4(rx, off[k], (uint32_t)ks * (KC * 4));
+        if constexpr (WIDE) xr[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, off[k], (uint32_t)ks * (KC * 4), 0));
+        else xr[k] = bld4(rx, off[k], (uint32_t)ks * (KC * 4));
     };
     auto load_x = [&](int ks) {
 #pragma unroll
@@ -385,26 +411,18 @@ __global__ __launch_bounds__(256, 1) void k_wino(WinoP p) {
                     asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_max_f32 %0, 0, %0\n\tv_cndmask_b32 %0, 0, %0, %3"
                                  : "+v"(xr[i * 4 + j][e]) : "v"(sc4[e]), "v"(sh4[e]), "s"(okm[i * 4 + j]));
         }
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const float d0 = xr[j][e], d1 = xr[4 + j][e], d2 = xr[8 + j][e], d3 = xr[12 + j][e];
-            xr[j][e] = d0 - d2; xr[4 + j][e] = d1 + d2; xr[8 + j][e] = d2 - d1; xr[12 + j][e] = d1 - d3;
+        {
+            const XT d0 = xr[j], d1 = xr[4 + j], d2 = xr[8 + j], d3 = xr[12 + j];
+            xr[j] = pk_sub(d0, d2); xr[4 + j] = pk_add(d1, d2); xr[8 + j] = pk_sub(d2, d1); xr[12 + j] = pk_sub(d1, d3);
         }
     };
     // row transform of patch row i and its four LDS stores
     auto row_store = [&](int i, int buf) {
         float* w = wbase + buf * (16 * TB * KC) + (i * 4) * (TB * KC);
-        f32x4 o[4];
+        const XT t0 = xr[i * 4], t1 = xr[i * 4 + 1], t2 = xr[i * 4 + 2], t3 = xr[i * 4 + 3];
+        const XT o[4] = {pk_sub(t0, t2), pk_add(t1, t2), pk_sub(t2, t1), pk_sub(t1, t3)};
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const float t0 = xr[i * 4][e], t1 = xr[i * 4 + 1][e], t2 = xr[i * 4 + 2][e], t3 = xr[i * 4 + 3][e];
-            o[0][e] = t0 - t2; o[1][e] = t1 + t2; o[2][e] = t2 - t1; o[3][e] = t1 - t3;
-        }
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-            if constexpr (WIDE) *reinterpret_cast<f32x2*>(w + nu * (TB * KC)) = f32x2{o[nu][0], o[nu][1]};
-            else *reinterpret_cast<f32x4*>(w + nu * (TB * KC)) = o[nu];
-        }
+        for (int nu = 0; nu < 4; ++nu) *reinterpret_cast<XT*>(w + nu * (TB * KC)) = o[nu];
     };
     auto ld_scale = [&](int ks, f32x4& sc4, f32x4& sh4) {
         if constexpr (XF) {
