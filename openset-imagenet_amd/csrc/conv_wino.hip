@@ -97,6 +97,16 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
     asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ f32x2 pk_neg(f32x2 a) {          // 0 - a (the sign of a zero aside, which no consumer here can tell)
+    f32x2 r;
+    asm volatile("v_pk_add_f32 %0, 0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
     const f32x2 lo = pk_add(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
     const f32x2 hi = pk_add(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
@@ -685,7 +695,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
     // texture addresser's queue (4 waves x 40 x 256 B: ~0.9 us per step, measured), spread over the positions of a step it is free.
     // raw operands of this wave, two register sets — 0: the step being transformed, 1: the step in flight —: 2 tiles x (16 patch pixels of x,
     // 4 pixels of dy) for the lane's channel + wave-uniform validity bits. Indexed by compile-time constants only.
-    float rx_[2][2][16], rd_[2][2][4];
+    // (one f32x2 per pixel: component = the wave's tile i2 — the two tiles of a wave go through the same arithmetic, so every add / fma of
+    // the transforms is ONE packed instruction for both: fp32 MFMAs hide no vector work, profiles/r06_mfma_valu_coexec.txt)
+    f32x2 rx_[2][16], rd_[2][4];
     unsigned okx_[2][2], okd_[2][2];
     uint32_t srb[2][4], scb[2][4], sdr[2][2], sdc[2][2];
     auto prep_step = [&](int st, auto SETC) {
@@ -723,9 +735,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
     auto issue_load = [&](auto NC, auto SETC) {
         constexpr int n = decltype(NC)::value, set = decltype(SETC)::value, i2 = n / 20, k = n % 20;
         if constexpr (k < 16)
-            rx_[set][i2][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xlane, srb[i2][k / 4] + scb[i2][k % 4], 0));
+            rx_[set][k][i2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xlane, srb[i2][k / 4] + scb[i2][k % 4], 0));
         else
-            rd_[set][i2][k - 16] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, dlane, sdr[i2][(k - 16) / 2] + sdc[i2][(k - 16) % 2], 0));
+            rd_[set][k - 16][i2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, dlane, sdr[i2][(k - 16) / 2] + sdc[i2][(k - 16) % 2], 0));
     };
     auto load_step = [&](int st, auto SETC) {       // the whole step at once (prologue)
         prep_step(st, SETC);
@@ -735,38 +747,46 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
     // LDS images. operand 0 = Yt (rows = couts), 1 = V (rows = cins); float index ((((buf * 2 + op) * 16 + pos) * 2 + h) * 64 + ch) * 4 + kk
     auto img = [&](int buf, int op, int pos, int h, int ch) { return sL + ((((buf * 2 + op) * 16 + pos) * 2 + h) * 64 + ch) * 4; };
     // activation of a tile's patch (padding / dead tiles selected to zero after it) and zeroing of dy pixels outside the image
-    auto act = [&](auto SETC, int i2) {
+    auto act = [&](auto SETC) {                // both tiles: one packed fma per pixel, max and the (wave-uniform) padding select per tile
         constexpr int set = decltype(SETC)::value;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const float v = XF ? fmaxf(__builtin_fmaf(rx_[set][i2][k], scsh[0], scsh[1]), 0.f) : rx_[set][i2][k];
-            rx_[set][i2][k] = ((okx_[set][i2] >> k) & 1u) ? v : 0.f;
+            f32x2 v = rx_[set][k];
+            if constexpr (XF) {
+                // v = v * scale + shift for both tiles: scale = the LOW half of the pair scsh for both lanes, shift = its HIGH half
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "+v"(v) : "v"(scsh));
+                // (asm: fmaxf on a value the compiler did not produce itself gets a canonicalising v_max in front of the real one)
+                asm volatile("v_max_f32 %0, 0, %0" : "+v"(v[0]));
+                asm volatile("v_max_f32 %0, 0, %0" : "+v"(v[1]));
+            }
+            v[0] = ((okx_[set][0] >> k) & 1u) ? v[0] : 0.f;
+            v[1] = ((okx_[set][1] >> k) & 1u) ? v[1] : 0.f;
+            rx_[set][k] = v;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rd_[set][i2][k] = ((okd_[set][i2] >> k) & 1u) ? rd_[set][i2][k] : 0.f;
+        for (int k = 0; k < 4; ++k) {
+            rd_[set][k][0] = ((okd_[set][0] >> k) & 1u) ? rd_[set][k][0] : 0.f;
+            rd_[set][k][1] = ((okd_[set][1] >> k) & 1u) ? rd_[set][k][1] : 0.f;
+        }
     };
-    auto col_x = [&](auto SETC, int i2) {      // B^T d: columns
+    auto col_x = [&](auto SETC) {      // B^T d: columns, both tiles
         constexpr int set = decltype(SETC)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float d0 = rx_[set][i2][j], d1 = rx_[set][i2][4 + j], d2 = rx_[set][i2][8 + j], d3 = rx_[set][i2][12 + j];
-            rx_[set][i2][j] = d0 - d2; rx_[set][i2][4 + j] = d1 + d2; rx_[set][i2][8 + j] = d2 - d1; rx_[set][i2][12 + j] = d1 - d3;
+            const f32x2 d0 = rx_[set][j], d1 = rx_[set][4 + j], d2 = rx_[set][8 + j], d3 = rx_[set][12 + j];
+            rx_[set][j] = pk_sub(d0, d2); rx_[set][4 + j] = pk_add(d1, d2); rx_[set][8 + j] = pk_sub(d2, d1); rx_[set][12 + j] = pk_sub(d1, d3);
         }
     };
     // (B^T d B) row i of both tiles -> V image; (A dY A^T) row i of both tiles -> Yt image. One 8-byte store per position and operand.
     auto row_store = [&](auto SETC, int i, int buf) {
         constexpr int set = decltype(SETC)::value;
-        f32x2 v[4], y[4];
-#pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2) {
-            const float t0 = rx_[set][i2][i * 4], t1 = rx_[set][i2][i * 4 + 1], t2 = rx_[set][i2][i * 4 + 2], t3 = rx_[set][i2][i * 4 + 3];
-            v[0][i2] = t0 - t2; v[1][i2] = t1 + t2; v[2][i2] = t2 - t1; v[3][i2] = t1 - t3;
-            // A = [[1,0],[1,1],[1,-1],[0,-1]]: rows of A dY:  r0 = dy0., r1 = dy0. + dy1., r2 = dy0. - dy1., r3 = -dy1.
-            const float a = rd_[set][i2][0], b = rd_[set][i2][1], c = rd_[set][i2][2], d = rd_[set][i2][3];
-            const float e0 = i == 0 ? a : i == 1 ? a + c : i == 2 ? a - c : -c;
-            const float e1 = i == 0 ? b : i == 1 ? b + d : i == 2 ? b - d : -d;
-            y[0][i2] = e0; y[1][i2] = e0 + e1; y[2][i2] = e0 - e1; y[3][i2] = -e1;
-        }
+        const f32x2 t0 = rx_[set][i * 4], t1 = rx_[set][i * 4 + 1], t2 = rx_[set][i * 4 + 2], t3 = rx_[set][i * 4 + 3];
+        const f32x2 v[4] = {pk_sub(t0, t2), pk_add(t1, t2), pk_sub(t2, t1), pk_sub(t1, t3)};
+        // A = [[1,0],[1,1],[1,-1],[0,-1]]: rows of A dY:  r0 = dy0., r1 = dy0. + dy1., r2 = dy0. - dy1., r3 = -dy1.
+        const f32x2 a = rd_[set][0], b = rd_[set][1], c = rd_[set][2], d = rd_[set][3];
+        const f32x2 e0 = i == 0 ? a : i == 1 ? pk_add(a, c) : i == 2 ? pk_sub(a, c) : pk_neg(c);
+        const f32x2 e1 = i == 0 ? b : i == 1 ? pk_add(b, d) : i == 2 ? pk_sub(b, d) : pk_neg(d);
+        const f32x2 y[4] = {e0, pk_add(e0, e1), pk_sub(e0, e1), pk_neg(e1)};
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
             *reinterpret_cast<f32x2*>(img(buf, 1, i * 4 + nu, lh, lane) + 2 * kkp) = v[nu];
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
     using S1 = std::integral_constant<int, 1>;
     load_step(0, S0{});
     load_step(p.steps > 1 ? 1 : 0, S1{});
-    act(S0{}, 0); act(S0{}, 1); col_x(S0{}, 0); col_x(S0{}, 1);
+    act(S0{}); col_x(S0{});
 #pragma unroll
     for (int i = 0; i < 4; ++i) row_store(S0{}, i, 0);
     __syncthreads();
@@ -803,13 +823,11 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
         const int buf = st & 1;
         {   // set 1 holds step st + 1 (loaded a full step ago): into set 0
 #pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2) {
+            for (int k = 0; k < 16; ++k) rx_[0][k] = rx_[1][k];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) rx_[0][i2][k] = rx_[1][i2][k];
+            for (int k = 0; k < 4; ++k) rd_[0][k] = rd_[1][k];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) rd_[0][i2][k] = rd_[1][i2][k];
-                okx_[0][i2] = okx_[1][i2]; okd_[0][i2] = okd_[1][i2];
-            }
+            for (int i2 = 0; i2 < 2; ++i2) { okx_[0][i2] = okx_[1][i2]; okd_[0][i2] = okd_[1][i2]; }
         }
 #if !(OSI_WABL & 1)
         prep_step(st + 2 < p.steps ? st + 2 : p.steps - 1, S1{});   // past the end: a valid step re-loaded (never used): no branch around loads
@@ -836,8 +854,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
             }
 #endif
 #if !(OSI_WABL & 2)
-            if constexpr (pos == TR0) { act(S0{}, 0); act(S0{}, 1); }
-            if constexpr (pos == TR0 + 1) { col_x(S0{}, 0); col_x(S0{}, 1); }
+            if constexpr (pos == TR0) act(S0{});
+            if constexpr (pos == TR0 + 1) col_x(S0{});
             if constexpr (pos >= 12) row_store(S0{}, pos - 12, buf ^ 1);
 #endif
             a0 = na; b0 = nb;
@@ -848,10 +866,15 @@ __global__ __launch_bounds__(256, 1) void k_wino_wgrad(WgradP p) {
     }
 
     // ---- epilogue: dW = G^T S G per (cout, cin), written as a partial in [9][64 cout][64 cin] order (lane = cin: 128-byte runs) ---------
-    float* out = p.slab + (size_t)item * (9 * 4096) + (32 * wn + l31);
+    // The lane's coordinates are taken afresh here (lane id from mbcnt, wave role from the scalar copies): kept from the top of the kernel
+    // they would have to live through the K loop, whose 256 + 256 registers are all taken (two spills otherwise).
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int hh_e = lane_e >> 5, l31_e = lane_e & 31;      // (kkp = wave >> 1 = wm, lh = wave & 1 = wn: wave-uniform scalars)
+    float* out = p.slab + (size_t)item * (9 * 4096) + (32 * lh + l31_e);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hh;          // cout row of accumulator register r
+        const int m = 32 * kkp + (r & 3) + 8 * (r >> 2) + 4 * hh_e;       // cout row of accumulator register r
         float t[3][4];
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
