@@ -46,6 +46,7 @@ def debug_options_from_env():
         OSI_DS_SPARSE=0       ds_sparse 0         stride-2 shortcut gradients written / read as dense tensors (zero fill included)
         OSI_STEM_WGRAD_MAIN=0 stem_wgrad_main 0   the fused stem weight gradient queued on the side stream behind layer1's weight gradients
         OSI_WINO_WEIGHTS_ASIDE=0 wino_weights_aside 0   the Winograd weight transforms of a training forward on the main stream (not beside the stem)
+        OSI_EVAL_FUSED=0      eval_fused 0        eval-mode forwards through the training topology on running statistics (no inference forms)
     (There is no switch for round 2's fused in-block activations: the unfused executor path no longer exists; its price on one box is the
     three-way A/B of the committed round-1 / round-2 / current trees, profiles/r03_ab_rounds.txt.)"""
     env = os.environ
@@ -73,6 +74,8 @@ def debug_options_from_env():
         out["wino_weights_aside"] = 0
     if env.get("OSI_STEM_WGRAD_MAIN") == "0":
         out["stem_wgrad_main"] = 0
+    if env.get("OSI_EVAL_FUSED") == "0":
+        out["eval_fused"] = 0
     return out
 
 
