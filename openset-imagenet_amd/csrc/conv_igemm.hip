@@ -415,6 +415,11 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     // MFMAs to shorten the load -> LDS window — fragments + transform temporaries live together spill 48-128 B per lane).
     auto xform = [&]() {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + ld_c0 + kq * 4), sh = *reinterpret_cast<const f32x4*>(s_sh + ld_c0 + kq * 4);
+        // 1x1 stride-1 (`unit`): there is no padding, the only invalid rows are those past M in the last row tile — their accumulator rows
+        // are never stored and the statistics mask them by row index (the K-split fix-up likewise), so the select after the activation
+        // is skipped: every vector instruction of an fp32-MFMA kernel is paid in matrix-pipe time (profiles/r06_mfma_valu_coexec.txt), and
+        // the bit test + compare + four selects per row were 14 of this loader's 30 per K tile. A uniform branch around arithmetic only.
+        const bool select = W3 || !p.unit;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             f32x4 v;
@@ -424,10 +429,15 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
                 if (XF == 2) t += rr[i][e];      // same two roundings as k_bn_apply<RES = 1>: fma, then add
                 v[e] = fmaxf(t, 0.f);
             }
-            // 1x1 stride-1: only rows past M are invalid and their results are never stored; otherwise padding taps must read as
-            // the zero the reference pads the ACTIVATION with
-            const bool ok = (((W3 ? (uint32_t)a_base[i] : a_taps[i]) >> ld_tap) & 1) != 0;
-            ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[i] = v;
+        }
+        if (select) {
+            // padding taps must read as the zero the reference pads the ACTIVATION with
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = (((W3 ? (uint32_t)a_base[i] : a_taps[i]) >> ld_tap) & 1) != 0;
+                ra[i] = ok ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     auto sstore = [&](int buf) {
@@ -1662,10 +1672,9 @@ __global__ __launch_bounds__(256, 4) void k_conv1x1_rows(ConvP p, int walkers) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x4 v = ra[kt][i];
-                if (XF) {
+                if (XF) {     // rows past M (last tile only) carry relu(shift): never stored, masked out of the statistics by row index
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], sc[e], sh[e]), 0.f);
-                    v = rok[i] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 *reinterpret_cast<f32x4*>(sA + kt * IMG + (lr + 32 * i) * LDR + kq * 4) = v;
             }
