@@ -25,6 +25,7 @@
 // k = 8j + 4h + e), which a dot product does not care about.
 #include "conv_common.h"
 #include <algorithm>
+#include <type_traits>
 
 using namespace osi_conv;
 
@@ -589,32 +590,42 @@ __global__ __launch_bounds__(256, XF ? (WM * WN == 1 ? 8 : 5) : (NST == 1 ? (WM 
     // the conv output): per column a (count, mean, M2) triple per 32x32 tile -> Chan-merged over the wave's tiles -> over the
     // two wave rows through LDS -> one (mean, M2) pair per column in pmean/pm2[mt][Cout]. Fixed order, no atomics.
     if (p.pmean) {
+        // Two code paths behind ONE uniform branch: a row tile that lies wholly inside the tensor (every tile of every network shape at
+        // the usual batches: M is a multiple of 64) needs no row masks — 16 compares and 32 selects per 32 x 32 accumulator block that are
+        // paid in matrix-pipe time (fp32 MFMAs hide no vector work, profiles/r06_mfma_valu_coexec.txt); same sums in the same order.
+        auto stats = [&](auto FULLC) {
+            constexpr bool full = decltype(FULLC)::value;
 #pragma unroll
-        for (int n = 0; n < WN; ++n) {
-            float cn = 0.f, cm = 0.f, cs = 0.f;
+            for (int n = 0; n < WN; ++n) {
+                float cn = 0.f, cm = 0.f, cs = 0.f;
 #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                const int row0 = m0 + wm * 32 * WM + i * 32;
-                const float cnt = (float)min(32, max(0, p.M - row0));
-                float s = 0.f;
+                for (int i = 0; i < WM; ++i) {
+                    const int row0 = m0 + wm * 32 * WM + i * 32;
+                    const float cnt = full ? 32.f : (float)min(32, max(0, p.M - row0));
+                    float s = 0.f;
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) s += (row0 + acc_row(rr, lane) < p.M) ? acc[i][n][rr] : 0.f;
-                s += __shfl_xor(s, 32, 64);
-                const float mu = cnt > 0.f ? s / cnt : 0.f;
-                float q = 0.f;
+                    for (int rr = 0; rr < 16; ++rr) s += (full || row0 + acc_row(rr, lane) < p.M) ? acc[i][n][rr] : 0.f;
+                    s += __shfl_xor(s, 32, 64);
+                    const float mu = cnt > 0.f ? s / cnt : 0.f;
+                    float q = 0.f;
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    const float dlt = acc[i][n][rr] - mu;
-                    q += (row0 + acc_row(rr, lane) < p.M) ? dlt * dlt : 0.f;
+                    for (int rr = 0; rr < 16; ++rr) {
+                        const float dlt = acc[i][n][rr] - mu;
+                        // (explicit fma in the unmasked path: the compiler would contract here and not there — the row walker and this
+                        // kernel must agree bit for bit)
+                        if constexpr (full) q = __builtin_fmaf(dlt, dlt, q);
+                        else q += (row0 + acc_row(rr, lane) < p.M) ? dlt * dlt : 0.f;
+                    }
+                    q += __shfl_xor(q, 32, 64);
+                    chan_merge(cn, cm, cs, cnt, mu, q);
                 }
-                q += __shfl_xor(q, 32, 64);
-                chan_merge(cn, cm, cs, cnt, mu, q);
+                if (lane < 32) {
+                    float* dst = smem + (wm * BN + wn * 32 * WN + n * 32 + lane) * 3;  // the K loop ended with a barrier: LDS is free
+                    dst[0] = cn; dst[1] = cm; dst[2] = cs;
+                }
             }
-            if (lane < 32) {
-                float* dst = smem + (wm * BN + wn * 32 * WN + n * 32 + lane) * 3;  // the K loop ended with a barrier: LDS is free
-                dst[0] = cn; dst[1] = cm; dst[2] = cs;
-            }
-        }
+        };
+        if (m0 + BM <= p.M) stats(std::true_type{}); else stats(std::false_type{});
         __syncthreads();
         if (tid < BN) {
             const float* a = smem + tid * 3;
@@ -703,6 +714,8 @@ __device__ __forceinline__ void dgrad_epilogue64(const ConvP& p, float* smem, in
             f32x4 v = rd(rl, c4);               // rows past Mc are exact zeros (their operand rows were range-checked loads)
             // sparse addend (a stride-2 1x1 branch wrote only the even-even pixels): elsewhere nothing is read. Computed without a
             // branch (st == 1 in that mode: pix = m = b*H*W + h*W + w), so that the rows stay one basic block
+            // (round 6: the decomposition behind a uniform branch on eadd_even — arithmetic only, the load outside — saves ~48 vector
+            // instructions per tile and costs four spilled registers: the join splits the block the rows' loads are scheduled in. Not kept.)
             const uint32_t apix = (uint32_t)(m0 + rl), ab = fdiv(apix, dHW), arem = apix - ab * dHW.d, ah = fdiv(arem, dW), aw = arem - ah * dW.d;
             const uint32_t aoff = (((ah | aw) & (uint32_t)p.eadd_even) != 0u) ? OOB : offb[k];   // eadd_even is 0 or 1: a mask, not a branch
             v += bld4(r_add, aoff, 0);          // may be the output buffer itself: read and written by the same lane
@@ -1289,15 +1302,19 @@ __global__ __launch_bounds__(256, NST == 1 ? (WM * WN == 4 ? 4 : (WM * WN == 2 ?
         const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + b_col), sh = *reinterpret_cast<const f32x4*>(s_sh + b_col);
 #pragma unroll
         for (int i = 0; i < BRN; ++i) {
-            const int row = b_row + BRP * i;
-            // A padding tap must read as zero AFTER the activation: select. Pixels past the split's end need nothing: their dY row
-            // is zero (range-checked load), so whatever finite value relu(shift) leaves in the X row is multiplied away — the 1x1
-            // stride-1 form has no padding and therefore no select at all.
-            const bool ok = (tbl[(ld_t % TW) * BK + row] != OOB) | (p.unit != 0);   // branch-free: the table read is issued either way
-            f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(rbv[i][e], sc[e], sh[e]), 0.f);
-            rbv[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < 4; ++e) rbv[i][e] = fmaxf(__builtin_fmaf(rbv[i][e], sc[e], sh[e]), 0.f);
+        }
+        // A padding tap must read as zero AFTER the activation: select. Pixels past the split's end need nothing: their dY row
+        // is zero (range-checked load), so whatever finite value relu(shift) leaves in the X row is multiplied away — the 1x1
+        // stride-1 form has no padding and therefore no select at all (a uniform branch around arithmetic only: vector instructions
+        // are paid in matrix-pipe time, profiles/r06_mfma_valu_coexec.txt).
+        if (!p.unit) {
+#pragma unroll
+            for (int i = 0; i < BRN; ++i) {
+                const bool ok = tbl[(ld_t % TW) * BK + b_row + BRP * i] != OOB;
+                rbv[i] = ok ? rbv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
 
@@ -1727,25 +1744,30 @@ __global__ __launch_bounds__(256, 4) void k_conv1x1_rows(ConvP p, int walkers) {
                     *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + c4 * 4) = *reinterpret_cast<const f32x4*>(sA + rl * LDT + c4 * 4);
             }
         }
-        if (p.pmean) {                   // BatchNorm (mean, M2) partials of this row tile's 64 columns (see k_conv_fwd)
-            const int row0 = m0 + wm * 32;
-            const float cnt = (float)min(32, max(0, p.M - row0));
-            float sm = 0.f;
+        if (p.pmean) {                   // BatchNorm (mean, M2) partials of this row tile's 64 columns (see k_conv_fwd: full tiles unmasked)
+            auto stats = [&](auto FULLC) {
+                constexpr bool full = decltype(FULLC)::value;
+                const int row0 = m0 + wm * 32;
+                const float cnt = full ? 32.f : (float)min(32, max(0, p.M - row0));
+                float sm = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) sm += (row0 + acc_row(rr, lane) < p.M) ? acc[0][0][rr] : 0.f;
-            sm += __shfl_xor(sm, 32, 64);
-            const float mu = cnt > 0.f ? sm / cnt : 0.f;
-            float q = 0.f;
+                for (int rr = 0; rr < 16; ++rr) sm += (full || row0 + acc_row(rr, lane) < p.M) ? acc[0][0][rr] : 0.f;
+                sm += __shfl_xor(sm, 32, 64);
+                const float mu = cnt > 0.f ? sm / cnt : 0.f;
+                float q = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const float dlt = acc[0][0][rr] - mu;
-                q += (row0 + acc_row(rr, lane) < p.M) ? dlt * dlt : 0.f;
-            }
-            q += __shfl_xor(q, 32, 64);
-            if (lane < 32) {
-                float* dst = s_st + (wm * BN + wn * 32 + lane) * 3;
-                dst[0] = cnt; dst[1] = mu; dst[2] = q;
-            }
+                for (int rr = 0; rr < 16; ++rr) {
+                    const float dlt = acc[0][0][rr] - mu;
+                    if constexpr (full) q = __builtin_fmaf(dlt, dlt, q);
+                    else q += (row0 + acc_row(rr, lane) < p.M) ? dlt * dlt : 0.f;
+                }
+                q += __shfl_xor(q, 32, 64);
+                if (lane < 32) {
+                    float* dst = s_st + (wm * BN + wn * 32 + lane) * 3;
+                    dst[0] = cnt; dst[1] = mu; dst[2] = q;
+                }
+            };
+            if (m0 + 64 <= p.M) stats(std::true_type{}); else stats(std::false_type{});
         }
         __syncthreads();                 // transposed tile read, statistics of both wave rows written
         if (p.pmean && tid < BN) {
