@@ -232,3 +232,36 @@ def test_predict_objectosphere_matches_reference_vectors(cuda, golden_dir):
         ref = G[f"po.{name}.result"]
         assert out.shape == ref.shape and np.array_equal(out[:, 0], ref[:, 0]), name
         assert np.allclose(out[:, 1], ref[:, 1], rtol=2e-6, atol=1e-7), name
+
+
+def test_sharded_validation_batches_through_the_prefetcher(cuda):
+    """Validation on every rank, data side (reference loader: train.py:306-311): the validation DataLoader built on
+    train.ShardedEvalBatches (rank r of `world`, sub-batches of batch / 4 that the prefetcher groups back, worker processes) yields
+    exactly the batches r, r + world, ... of the plain unshuffled loader of the same batch size — ragged last batch included."""
+    from openset_imagenet import tools, pipeline as P
+    from openset_imagenet.train import ShardedEvalBatches
+    tools.set_device_gpu(0)
+    g = torch.Generator().manual_seed(9)
+    n, B = 54, 8                                  # 7 batches, the last of 6 samples (two sub-batches: 2 + 2 + 2 -> 3 pieces of 2)
+    canv = torch.randint(0, 256, (n, 256, 256, 3), dtype=torch.uint8, generator=g)
+    crop = torch.randint(0, 33, (n, 2), generator=g).to(torch.int32)
+    flip = torch.zeros(n, dtype=torch.uint8)
+    lab = torch.arange(n)
+    ds = torch.utils.data.TensorDataset(canv, crop, flip, lab)
+    whole = [(x.clone(), y.clone()) for x, y in P.DevicePrefetcher(torch.utils.data.DataLoader(ds, batch_size=B, pin_memory=True))]
+    assert len(whole) == 7 and whole[-1][1].numel() == 6
+    for world, sub, nw in ((2, 4, 0), (4, 4, 2), (4, 1, 0), (8, 2, 0)):
+        seen = {}
+        for rank in range(world):
+            sampler = ShardedEvalBatches(n, B, rank, world, sub)
+            kw = dict(num_workers=nw, pin_memory=True)
+            if nw:
+                kw.update(persistent_workers=False, prefetch_factor=2)
+            loader = P.DevicePrefetcher(torch.utils.data.DataLoader(ds, batch_sampler=sampler, **kw), group=sub)
+            mine = [(x.clone(), y.clone()) for x, y in loader]
+            assert len(mine) == len(sampler.batches()) == len(loader)
+            for k, (x, y) in zip(sampler.batches(), mine):
+                seen[k] = (x, y)
+        assert sorted(seen) == list(range(7)), (world, sub)
+        for k, (x, y) in seen.items():
+            assert torch.equal(y, whole[k][1]) and torch.equal(x, whole[k][0]), (world, sub, k)
