@@ -176,3 +176,26 @@ def test_bench_dp_reserved_cus_reaches_the_launch_plan(cuda):
                      {"OSI_DP_RESERVED_CUS": "8"}, 1)
     lp = out["rccl"]["launch_plan"]
     assert lp["dp_reserved_cus"] == 8 and lp["tail_plan_cus_in_effect"] == 248
+
+
+@pytest.mark.timeout(900)
+def test_bench_record_says_what_its_roofline_measures_and_carries_the_inference_leg(cuda):
+    """`roofline.frac` is the EFFECTIVE rate (the direct convolution's FLOPs); `issued_frac` the matrix pipe's own
+    (Winograd layers issue 4/9 of their multiplies); the committed counter summary is cited with its provenance and withheld when it
+    belongs to another workload / batch; the `eval` object compares the inference forms with the training topology (never part of `value`)."""
+    out = _run_bench(["--steps", "2", "--warmup", "1", "--windows", "1", "--batch", "8", "--no-cpu-baseline", "--eval-steps", "2"], {}, 1)
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and 0 < r["issued_frac"] < r["frac"]
+    # B = 8: 24.287 GFLOP per image of direct convolution; the 13 Winograd layers issue 16 products per 2x2 tile instead of 36
+    assert r["issued_gflop_per_step"] == pytest.approx(8 * 2491.657 / 128, rel=1e-3)
+    assert set(r["issued_per_class_gflop"]) == {"conv_fwd", "conv_dgrad", "conv_wgrad"} and "EFFECTIVE" in r["frac_is"]
+    prov = r["mfma_busy_provenance"]
+    assert prov["file"].startswith("profiles/r") and len(prov["git_blob"]) == 40 and prov["matches_this_run"] is False   # the profile is B = 128
+    assert r["mfma_busy_percent"] is None and r["issued_gflop_per_step_measured"] is None and r["traffic"] is None
+    e = out["eval"]
+    assert e["batch"] == 8 and e["steps"] == 2
+    for k in ("training_topology", "fused", "validate_step"):
+        assert e[k]["images_per_sec"] > 0 and e[k]["ms_per_batch"] > 0
+    assert e["fused"]["serialized"]["launch_groups"] < e["training_topology"]["serialized"]["launch_groups"]
+    assert e["speedup"] == pytest.approx(e["training_topology"]["ms_per_batch"] / e["fused"]["ms_per_batch"], rel=1e-2)
+    assert out["value"] == pytest.approx(8 / (out["ms_per_step"] * 1e-3), rel=1e-2), "`value` comes from the timed windows alone"
