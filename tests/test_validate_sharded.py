@@ -92,6 +92,8 @@ def _worker(rank, world, port, out, mode):
                 model.bn.running_var.copy_(torch.rand(12, generator=torch.Generator().manual_seed(60 + rank)) + 0.5)
             g = torch.Generator().manual_seed(3)
             sizes = [B] * 6 + [3]                     # 7 batches, ragged tail: world 2 -> 4 + 3, world 4 -> 2 + 2 + 2 + 1
+            if mode == "short":                       # fewer batches than ranks: ranks 2 and 3 of 4 have nothing to score and still take part
+                sizes = [B, 3]
             batches = []
             for n in sizes:
                 y = torch.randint(0, C, (n,), generator=g)
@@ -105,7 +107,7 @@ def _worker(rank, world, port, out, mode):
                 loss_fn = lambda z, y: LO.garbage_loss(z, y, w)
             cfg = NameSpace({"parallel": True, "batch_size": B, "loss": {"type": loss_type}})
             mk = lambda: {"j": L.AverageMeter(), "conf_kn": L.AverageMeter(), "conf_unk": L.AverageMeter()}
-            if mode == "parity":
+            if mode in ("parity", "short"):
                 sharded = mk()
                 T.validate(model, batches[rank::world], loss_fn, C, sharded, cfg, shard=(rank, world))
                 assert not model.training
@@ -158,6 +160,15 @@ def test_sharded_validation_is_bit_identical_to_the_single_process_loop(world):
     for loss_type in ("entropic", "garbage"):
         per_rank = [m for _, lt, m in res if lt == loss_type]
         assert len(per_rank) == world and all(m == per_rank[0] for m in per_rank), "every rank ends with the same trackers"
+
+
+@pytest.mark.timeout(600)
+def test_ranks_without_a_batch_still_end_with_the_trackers():
+    res = _run(4, "short")
+    for loss_type in ("entropic", "garbage"):
+        per_rank = [m for _, lt, m in res if lt == loss_type]
+        assert len(per_rank) == 4 and all(m == per_rank[0] for m in per_rank)
+        assert per_rank[0]["j"][3] == 11
 
 
 @pytest.mark.timeout(600)
