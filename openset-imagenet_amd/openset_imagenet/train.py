@@ -195,7 +195,7 @@ def validate(model, data_loader, loss_fn, n_classes, trackers, cfg, shard=None):
         rank, world = int(shard[0]), int(shard[1])
         group = shard[2] if len(shard) > 2 else None
     model.eval()
-    losses, counts, rows, chunks = [], [], [], []
+    losses, counts, rows, chunks, records = [], [], [], [], []
     error = None
     try:
         if world > 1:
@@ -213,14 +213,13 @@ def validate(model, data_loader, loss_fn, n_classes, trackers, cfg, shard=None):
                 row = chunks[-1][len(rows) % 256]
                 _confidence_partial(logits, labels, min_unk_score, unknown_class, last_valid, row)
                 rows.append(row)
+        if losses:                         # the one synchronisation of the loop (an asynchronous device error surfaces here: still inside the try)
+            conf = torch.cat(chunks)[:len(rows)].cpu().tolist()
+            records = [(rank + k * world, v, n, c) for k, (v, n, c) in enumerate(zip(torch.stack(losses).cpu().tolist(), counts, conf))]
     except Exception as e:                 # under data parallel the other ranks wait in the gather below: tell them there
         if world == 1:
             raise
-        error = e
-    records = []
-    if losses and error is None:
-        conf = torch.cat(chunks)[:len(rows)].cpu().tolist()
-        records = [(rank + k * world, v, n, c) for k, (v, n, c) in enumerate(zip(torch.stack(losses).cpu().tolist(), counts, conf))]
+        error, records = e, []
     if world > 1:
         import torch.distributed as dist
         everyone = [None] * world
