@@ -625,7 +625,9 @@ int osi_resnet50_forward(osi_resnet50_t n, const float* params, float* buffers, 
     // On the side stream beside the stem (26 launches of 4 - 16 us that used to sit in front of their convolutions); the first Winograd
     // convolution waits for them.
     if (n->plan_knobs.fwd_wino || (training && n->plan_knobs.dgrad_wino)) {
-        const bool aside = n->async_wgrad() && n->wt_aside;
+        // (training forwards only: an inference forward has 13 transforms and nothing but the stem beside them — the fork / join costs more
+        // than they do: 7.96 in line vs 8.00 ms aside per batch of 128, profiles/NOTES_r06.md)
+        const bool aside = training && n->async_wgrad() && n->wt_aside;
         hipStream_t wt = aside ? n->side : st;
         if (aside) {
             if (hipEventRecord(n->ev_fork, st) != hipSuccess) return OSI_ERR_LAUNCH;
